@@ -1,0 +1,87 @@
+"""ctypes binding of libgandtr_hip.so (C ABI: include/gandtr_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` / ``make -C gandtr_amd/csrc``.  There is NO
+fallback: if the library is missing the HIP path raises -- a CUDA/HIP device request never silently runs torch ops.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgandtr_hip.so")
+_lib = None
+
+GDT_OK, GDT_ERR_INVALID, GDT_ERR_HIP, GDT_ERR_WORKSPACE = 0, 1, 2, 3
+
+
+class ConvDesc(ctypes.Structure):
+    """struct gdt_conv_desc (include/gandtr_hip.h)."""
+    _fields_ = [("cin", c_int), ("cout", c_int), ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int),
+                ("pad_reflect", c_int), ("transposed", c_int), ("relu", c_int), ("out_f32_nchw", c_int),
+                ("act", c_int), ("bn_eps", c_float)]
+
+
+_FP = POINTER(c_float)
+_IP = POINTER(c_int)
+
+# name -> (restype, argtypes); every symbol declared in include/gandtr_hip.h
+SIGNATURES = {
+    "gdt_last_error": (c_char_p, []),
+    "gdt_version": (c_char_p, []),
+    "gdt_net_create": (c_int, [POINTER(c_void_p)]),
+    "gdt_net_destroy": (None, [c_void_p]),
+    "gdt_net_input": (c_int, [c_void_p, c_int, _IP, _FP, _FP, _IP]),
+    "gdt_net_conv": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_int, _IP]),
+    "gdt_net_instance_norm": (c_int, [c_void_p, c_int, c_float, c_int, c_int, _IP]),
+    "gdt_net_maxpool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP]),
+    "gdt_net_gem_l2n": (c_int, [c_void_p, c_int, c_float, c_float, c_float, _IP]),
+    "gdt_net_output_nchw": (c_int, [c_void_p, c_int, c_void_p, _IP]),
+    "gdt_net_hed_head": (c_int, [c_void_p, _IP, POINTER(c_void_p), _FP, _FP, c_float, c_int, _IP]),
+    "gdt_net_finalize": (c_int, [c_void_p]),
+    "gdt_net_output_shape": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, _IP]),
+    "gdt_net_num_outputs": (c_int, [c_void_p]),
+    "gdt_net_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "gdt_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p),
+                                c_int, c_void_p, c_size_t, c_void_p]),
+    "gdt_net_flops": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
+    "gdt_ms_aggregate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "gdt_whiten": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gdt_l2n_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises HipLibraryMissing when the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found: the gandtr HIP path has no CPU fallback. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gandtr_amd/csrc`." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here == ABI mismatch between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Translate a gdt status into the exception type the reference raises for the same condition
+    (ValueError for bad arguments / unsupported shapes, RuntimeError for device failures)."""
+    if rc == GDT_OK:
+        return
+    msg = load().gdt_last_error().decode("utf8", "replace")
+    if rc == GDT_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError("gandtr_hip error %d: %s" % (rc, msg))

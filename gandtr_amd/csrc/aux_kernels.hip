@@ -1,0 +1,415 @@
+// HBM-bound helper kernels of the gandtr hot path (gfx950).  All activations are NHWC fp16; every lane moves 16 B.
+//
+//   pack_input      fp32 NCHW image -> fp16 NHWC8, optional bilinear resize (F.interpolate(scale_factor=s,
+//                   mode='bilinear', align_corners=False), mdir/components/data/wrapper.py:225), channel permutation
+//                   (RgbToBgrPre wrapper.py:351-364) and per-channel affine (MeanStdPost._adapt wrapper.py:172-175)
+//   in_stats / in_finalize / in_apply
+//                   nn.InstanceNorm2d(affine=False), eps 1e-5, biased variance (p2p_networks.py:29) + fused ReLU
+//                   (:272) + fused residual add (ResnetBlock.forward :505)
+//   maxpool         nn.MaxPool2d(2,2) (VGG16, HED hed.py:53) and (3,2,1) (ResNet-101 stem)
+//   gem / l2n       cirtorch layers/functional.py:21-22, :130-131
+//   ms_aggregate    CirMultiscaleAggregation.aggregate_tensor wrapper.py:236-245
+//   whiten          CirtorchWhiten.postprocess wrapper.py:320-322
+//   unpack_output   fp16 NHWC -> fp32 NCHW (feature taps, p2p_networks.py:316-334)
+//   hed_score / hed_fuse   1x1 score convs, bilinear upsampling to the input size, 1x1 fusion, sigmoid (hed.py:67-83)
+#include "gdt_common.h"
+#include "aux_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ pack_input
+struct PackArgs {
+    const float* x; f16* y;
+    int N, C, H, W, OH, OW;
+    float rscale;          // 1 / scale_factor (torch's source-index scale when scale_factor is given)
+    int resize;
+    int perm[8]; float scale[8], shift[8];
+};
+
+__global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a) {
+    const long total = (long)a.N * a.OH * a.OW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % a.OW);
+        const long t = i / a.OW;
+        const int oy = (int)(t % a.OH), n = (int)(t / a.OH);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (f16)0.f;
+        if (!a.resize) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < a.C) {
+                    const float v = a.x[(((long)n * a.C + a.perm[c]) * a.H + oy) * a.W + ox];
+                    o[c] = (f16)(v * a.scale[c] + a.shift[c]);
+                }
+        } else {
+            // aten area_pixel_compute_source_index(align_corners=False): src = scale * (dst + 0.5) - 0.5, clamped at 0
+            float sy = a.rscale * (oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+            float sx = a.rscale * (ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+            const float ly1 = sy - y0, ly0 = 1.f - ly1, lx1 = sx - x0, lx0 = 1.f - lx1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < a.C) {
+                    const float* p = a.x + ((long)n * a.C + a.perm[c]) * a.H * a.W;
+                    const float v = ly0 * (lx0 * p[(long)y0 * a.W + x0] + lx1 * p[(long)y0 * a.W + x1]) +
+                                    ly1 * (lx0 * p[(long)y1 * a.W + x0] + lx1 * p[(long)y1 * a.W + x1]);
+                    o[c] = (f16)(v * a.scale[c] + a.shift[c]);
+                }
+        }
+        *(f16x8*)(a.y + i * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ InstanceNorm
+// stage 1: per (image, pixel chunk) partial sum / sum of squares for every channel.  partial[n][chunk][2][C]
+__global__ __launch_bounds__(256) void in_stats_kernel(const f16* __restrict__ x, float* __restrict__ partial,
+                                                       int HW, int C, int chunk_px) {
+    __shared__ float red[256 * 16];
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int c8n = C >> 3;                       // 16-byte chunks per pixel
+    const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n, nprow = 256 / c8n;
+    const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (prow < nprow) {
+        const f16* base = x + ((long)n * HW) * C + c8 * 8;
+        for (int p = p0 + prow; p < p1; p += nprow) {
+            const f16x8 v = *(const f16x8*)(base + (long)p * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s[e]; red[threadIdx.x * 16 + 8 + e] = q[e]; }
+    __syncthreads();
+    // fixed-order reduction over pixel rows (deterministic)
+    for (int o = threadIdx.x; o < C * 2; o += 256) {
+        const int which = o / C, c = o % C;
+        float acc = 0.f;
+        for (int r = 0; r < nprow; ++r) acc += red[(r * c8n + (c >> 3)) * 16 + which * 8 + (c & 7)];
+        partial[(((long)n * nchunks + chunk) * 2 + which) * C + c] = acc;
+    }
+}
+
+// stage 2: mean / rstd per (n, c); fp64 accumulation over the chunk partials, biased variance.
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
+                                                          int nchunks, int C, int HW, float eps, int NC) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i % C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        s += (double)partial[(((long)n * nchunks + k) * 2 + 0) * C + c];
+        q += (double)partial[(((long)n * nchunks + k) * 2 + 1) * C + c];
+    }
+    const double m = s / HW;
+    double var = q / HW - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean_rstd[(long)i * 2 + 0] = (float)m;
+    mean_rstd[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// stage 3: y = relu?((x - mean) * rstd) (+ residual)
+__global__ __launch_bounds__(256) void in_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                       const f16* __restrict__ res, f16* __restrict__ y,
+                                                       long HW, int C, int relu, long total8) {
+    const int c8n = C >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        const long n = (i / c8n) / HW;
+        const float* mr = mean_rstd + (n * C + c8 * 8) * 2;
+        f16x8 v = *(const f16x8*)(x + i * 8);
+        f16x8 r;
+        if (res) r = *(const f16x8*)(res + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = ((float)v[e] - mr[2 * e]) * mr[2 * e + 1];
+            if (relu) f = fmaxf(f, 0.f);
+            if (res) f += (float)r[e];
+            v[e] = (f16)f;
+        }
+        *(f16x8*)(y + i * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max pooling
+__global__ __launch_bounds__(256) void maxpool_kernel(const f16* __restrict__ x, f16* __restrict__ y, int N, int H, int W,
+                                                      int C, int OH, int OW, int k, int s, int p) {
+    const int c8n = C >> 3;
+    const long total = (long)N * OH * OW * c8n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        long t = i / c8n;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH), n = (int)(t / OH);
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * s - p + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * s - p + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f16x8 v = *(const f16x8*)(x + (((long)n * H + iy) * W + ix) * C + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *(f16x8*)(y + i * 8) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GeM + L2N
+// grid (D/64, N); 8 lanes cover 64 channels (16 B each), 32 pixel rows per pass; fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void gem_kernel(const f16* __restrict__ x, float* __restrict__ pooled, int HW, int D,
+                                                  float p, float eps) {
+    __shared__ float red[32][64];
+    const int n = blockIdx.y, d0 = blockIdx.x * 64;
+    const int c8 = threadIdx.x & 7, prow = threadIdx.x >> 3;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const f16* base = x + (long)n * HW * D + d0 + c8 * 8;
+    const bool cube = (p == 3.0f);
+    for (int px = prow; px < HW; px += 32) {
+        const f16x8 v = *(const f16x8*)(base + (long)px * D);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = fmaxf((float)v[e], eps);
+            s[e] += cube ? f * f * f : powf(f, p);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[prow][c8 * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float acc = 0.f;
+        for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+        pooled[(long)n * D + d0 + threadIdx.x] = powf(acc / HW, 1.0f / p);
+    }
+}
+
+// y[n][:] = x[n][:] / (||x[n]||_2 + eps); one workgroup per row
+__global__ __launch_bounds__(256) void l2n_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int D, float eps) {
+    __shared__ float red[4];
+    const float* xr = x + (long)blockIdx.x * D;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) s += xr[i] * xr[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]) + eps;
+    for (int i = threadIdx.x; i < D; i += 256) y[(long)blockIdx.x * D + i] = xr[i] / nrm;
+}
+
+// v[n][d] = (mean_s x[s][n][d]^msp)^(1/msp); then v /= ||v|| (no eps)
+__global__ __launch_bounds__(256) void ms_aggregate_kernel(const float* __restrict__ x, float* __restrict__ y, int S, int N,
+                                                           int D, float msp) {
+    __shared__ float red[4];
+    extern __shared__ float vbuf[];
+    const int n = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += powf(x[((long)s * N + n) * D + i], msp);
+        const float v = powf(acc / S, 1.0f / msp);
+        vbuf[i] = v;
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x; i < D; i += 256) y[(long)n * D + i] = vbuf[i] / nrm;
+}
+
+// X[n][r] = sum_d P[r][d] * (v[n][d] - m[d]) for r < dims; one wavefront per (row, image)
+__global__ __launch_bounds__(256) void whiten_matvec_kernel(const float* __restrict__ P, const float* __restrict__ m,
+                                                            const float* __restrict__ v, float* __restrict__ X, int D, int dims) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y, lane = threadIdx.x & 63;
+    if (r >= dims) return;
+    const float* pr = P + (long)r * D;
+    const float* vr = v + (long)n * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += pr[d] * (vr[d] - m[d]);
+    s = wave_sum(s);
+    if (lane == 0) X[(long)n * dims + r] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ taps / outputs
+__global__ __launch_bounds__(256) void unpack_output_kernel(const f16* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ bias, int N, int HW, int C) {
+    const long total = (long)N * C * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const long t = i / HW;
+        const int c = (int)(t % C), n = (int)(t / C);
+        y[i] = (float)x[((long)n * HW + p) * C + c] + (bias ? bias[c] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ HED head
+// score[n][p] = b + sum_c x[n][p][c] * w[c]; one wavefront per pixel group of 8 (8 lanes per pixel)
+__global__ __launch_bounds__(256) void hed_score_kernel(const f16* __restrict__ x, const float* __restrict__ w, float bias,
+                                                        float* __restrict__ score, long NP, int C) {
+    const long p = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    float s = 0.f;
+    if (p < NP) {
+        const f16* xr = x + p * C;
+        for (int c = sub * 8; c < C; c += 64) {
+            const f16x8 v = *(const f16x8*)(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[e] * w[c + e];
+        }
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (p < NP && sub == 0) score[p] = s + bias;
+}
+
+struct HedFuseArgs {
+    const float* score[5]; int h[5], w[5];
+    float fw[5], fb;
+    float* out; int N, H, W, sigmoid;
+};
+
+// F.interpolate(size=(H,W), mode='bilinear', align_corners=False) of each score map (scale = in/out), 1x1 fusion, sigmoid
+__global__ __launch_bounds__(256) void hed_fuse_kernel(const HedFuseArgs a) {
+    const long total = (long)a.N * a.H * a.W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ox = (int)(i % a.W);
+        const long t = i / a.W;
+        const int oy = (int)(t % a.H), n = (int)(t / a.H);
+        float acc = a.fb;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int h = a.h[k], w = a.w[k];
+            const float ry = (float)h / a.H, rx = (float)w / a.W;
+            float sy = ry * (oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+            float sx = rx * (ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float ly1 = sy - y0, ly0 = 1.f - ly1, lx1 = sx - x0, lx0 = 1.f - lx1;
+            const float* p = a.score[k] + (long)n * h * w;
+            const float v = ly0 * (lx0 * p[y0 * w + x0] + lx1 * p[y0 * w + x1]) + ly1 * (lx0 * p[y1 * w + x0] + lx1 * p[y1 * w + x1]);
+            acc += a.fw[k] * v;
+        }
+        a.out[i] = a.sigmoid ? 1.f / (1.f + expf(-acc)) : acc;
+    }
+}
+
+inline int grid_for(long work_items, int cap = 256 * 16) {
+    long g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// ================================================================================================ launchers
+int gdt_k_pack_input(const float* x, f16* y, int N, int C, int H, int W, int OH, int OW, float rscale, int resize,
+                     const int* perm, const float* scale, const float* shift, hipStream_t st) {
+    GDT_REQUIRE(C >= 1 && C <= 8, "pack_input supports 1..8 channels");
+    PackArgs a;
+    a.x = x; a.y = y; a.N = N; a.C = C; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.rscale = rscale; a.resize = resize;
+    for (int c = 0; c < 8; ++c) {
+        a.perm[c] = (perm && c < C) ? perm[c] : (c < C ? c : 0);
+        a.scale[c] = (scale && c < C) ? scale[c] : 1.f;
+        a.shift[c] = (shift && c < C) ? shift[c] : 0.f;
+    }
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((long)N * OH * OW)), dim3(256), 0, st, a);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_in_stats_chunks(int HW) { int c = (HW + 1023) / 1024; return c < 1 ? 1 : c; }
+
+int gdt_k_instance_norm(const f16* x, const f16* res, f16* y, float* partial, float* mean_rstd, int N, int HW, int C,
+                        float eps, int relu, hipStream_t st) {
+    GDT_REQUIRE(C % 8 == 0 && C <= 2048 && (256 % (C / 8) == 0 || C / 8 > 256), "InstanceNorm channel count");
+    GDT_REQUIRE(C / 8 <= 256, "InstanceNorm supports C <= 2048");
+    const int nchunks = gdt_in_stats_chunks(HW);
+    const int chunk_px = (HW + nchunks - 1) / nchunks;
+    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunks, N), dim3(256), 0, st, x, partial, HW, C, chunk_px);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, partial, mean_rstd, nchunks, C, HW,
+                       eps, N * C);
+    GDT_CHECK_HIP(hipGetLastError());
+    const long total8 = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, mean_rstd, res, y, (long)HW, C, relu,
+                       total8);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_maxpool(const f16* x, f16* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
+    GDT_REQUIRE(C % 8 == 0, "maxpool needs C % 8 == 0");
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long)N * OH * OW * (C / 8))), dim3(256), 0, st, x, y, N, H, W, C, OH,
+                       OW, k, s, p);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_gem_l2n(const f16* x, float* pooled, float* out, int N, int HW, int D, float p, float eps_gem, float eps_l2,
+                  hipStream_t st) {
+    GDT_REQUIRE(D % 64 == 0, "GeM needs D % 64 == 0");
+    hipLaunchKernelGGL(gem_kernel, dim3(D / 64, N), dim3(256), 0, st, x, pooled, HW, D, p, eps_gem);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)pooled, out, D, eps_l2);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_l2n_rows(const float* x, float* y, int N, int D, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, x, y, D, eps);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_ms_aggregate(const float* x, float* y, int S, int N, int D, float msp, hipStream_t st) {
+    GDT_REQUIRE(D * sizeof(float) <= 48 * 1024, "ms_aggregate: D too large");
+    hipLaunchKernelGGL(ms_aggregate_kernel, dim3(N), dim3(256), D * sizeof(float), st, x, y, S, N, D, msp);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_whiten(const float* P, const float* m, const float* v, float* tmp, float* out, int N, int D, int dims,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(whiten_matvec_kernel, dim3((dims + 3) / 4, N), dim3(256), 0, st, P, m, v, tmp, D, dims);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)tmp, out, dims, 1e-6f);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_unpack_output(const f16* x, float* y, const float* bias, int N, int HW, int C, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, st, x, y, bias, N, HW, C);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_hed_score(const f16* x, const float* w, float bias, float* score, long NP, int C, hipStream_t st) {
+    GDT_REQUIRE(C % 8 == 0, "hed_score needs C % 8 == 0");
+    hipLaunchKernelGGL(hed_score_kernel, dim3((int)((NP + 31) / 32)), dim3(256), 0, st, x, w, bias, score, NP, C);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_hed_fuse(const float* const* score, const int* h, const int* w, const float* fw, float fb, float* out, int N, int H,
+                   int W, int sigmoid, hipStream_t st) {
+    HedFuseArgs a;
+    for (int k = 0; k < 5; ++k) { a.score[k] = score[k]; a.h[k] = h[k]; a.w[k] = w[k]; a.fw[k] = fw[k]; }
+    a.fb = fb; a.out = out; a.N = N; a.H = H; a.W = W; a.sigmoid = sigmoid;
+    hipLaunchKernelGGL(hed_fuse_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, st, a);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}

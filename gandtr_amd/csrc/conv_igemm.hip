@@ -1,0 +1,253 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): fp16 NHWC activations x fp16 packed weights -> fp32 MFMA accumulate.
+//
+// Replaces every nn.Conv2d / nn.ConvTranspose2d on the gandtr hot path:
+//   generator  mdir/components/model/network/p2p_networks.py:269-311, ResnetBlock :480-494
+//   embedders  torchvision VGG16 / ResNet-101 trunks sliced at external/cirtorch/networks/imageretrievalnet.py:185-190
+//   HED        mdir/components/model/network/hed.py:50-58
+//
+// GEMM view: M = N*OHg*OWg output positions, N = Cout, K = taps*Cin (k = tap*Cin + c).
+//   A[m][k] = in[n][oy*sy+dy(tap)][ox*sx+dx(tap)][c]  (zero or reflect padding resolved per 16-byte chunk)
+//   B[k][n] = w[n][k]
+// Tile BM x BN x 64 per workgroup, 4 wavefronts (64 lanes each), v_mfma_f32_32x32x16_f16.
+// Both operands are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip); the LDS image is
+// linear per wave-instruction, so the bank-conflict XOR swizzle is applied on the SOURCE chunk index and again on
+// the ds_read_b128 address (chunk' = chunk ^ ((row >> 1) & 7)), which is conflict-free for the 32x32x16 fragment
+// reads.  Two LDS stages, one barrier per K-step: the loads of step k+1 are in flight while step k computes.
+#include "gdt_common.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int BK = 64;           // K-step (halves) = 128 B per tile row
+constexpr int ROWB = BK * 2;     // bytes per LDS tile row
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
+    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;     // per-wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;       // 32x32 MFMA tiles per wave
+    constexpr int AR = BM / 32, BR = BN / 32;         // loader rounds (32 rows per round for 256 threads)
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // block -> (tile_m, tile_n): N-tiles of the same M-tile are 8 blocks apart, i.e. on the same XCD under the
+    // observed round-robin dispatch, so the shared A rows are served by one L2 (speed only, never correctness).
+    const int ntn = d.CoutPad / BN;
+    int tile_m, tile_n;
+    {
+        const int b = blockIdx.x;
+        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
+        tile_m = grp * 8 + (rem & 7);
+        tile_n = rem >> 3;
+        const int ntm = (d.M + BM - 1) / BM;
+        if (tile_m >= ntm) return;   // grid is padded to a multiple of 8 M-tiles
+    }
+
+    // ---- per-thread loader state: this thread stages 16-byte chunk (lane & 7) of rows r = round*32 + wave*8 + lane/8
+    const int lrow = wave * 8 + (lane >> 3);
+    const int swz = (lrow >> 1) & 7;                  // same for every round (round*32 >> 1 is a multiple of 8)
+    const int q = (lane & 7) ^ swz;                   // source chunk (8 halves of K) this lane fetches
+    const int hw_g = d.OHg * d.OWg;
+    int a_base[AR];                                   // pixel index of image n's first pixel (N*H*W < 2^31)
+    int a_iy0[AR], a_ix0[AR];
+    unsigned a_valid = 0;                             // bit r: row of round r is inside M
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        const int m = tile_m * BM + r * 32 + lrow;
+        const int mm = m < d.M ? m : 0;
+        const int n = mm / hw_g, rem = mm - n * hw_g;
+        const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+        a_base[r] = n * d.H * d.W;
+        a_iy0[r] = oy * d.sy;
+        a_ix0[r] = ox * d.sx;
+        a_valid |= (m < d.M ? 1u : 0u) << r;
+    }
+    const f16* b_src = d.w + ((long)(tile_n * BN + lrow) * d.Kpad + q * 8);
+    const int cmask = (1 << d.lc8) - 1;
+
+    auto issue = [&](int ks, int stage) {
+        char* As = smem + stage * A_BYTES;
+        char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
+        // A: decode (tap, channel chunk) of this lane's K chunk
+        const int k8 = ks * 8 + q;
+        const int tap = k8 >> d.lc8, c8 = k8 & cmask;
+        const int ty = (tap * d.invTW) >> 16, tx = tap - ty * d.TW;
+        const int dy = d.dy0 + ty * d.dys, dx = d.dx0 + tx * d.dxs;
+        const bool tap_ok = tap < d.ntaps;
+        const bool refl = d.pad_reflect != 0;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            // branch-free padding: compute the reflected index and the in-bounds predicate, select afterwards
+            const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
+            const int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+            const int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+            const bool ok = tap_ok & (((a_valid >> r) & 1u) != 0) & (inb | refl);
+            const int pix = a_base[r] + ry * d.W + rx;       // reflected == identity when in bounds
+            const f16* src = d.in + (((long)pix << (d.lc8 + 3)) + c8 * 8);
+            glds16(ok ? src : d.zeros, As + (r * 32 + wave * 8) * ROWB);
+        }
+#pragma unroll
+        for (int r = 0; r < BR; ++r)
+            glds16(b_src + ((long)r * 32 * d.Kpad + ks * BK), Bs + (r * 32 + wave * 8) * ROWB);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment read addresses (row part); chunk part is XORed per k16 step
+    const int fr = lane & 31, fh = lane >> 5;
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + fr;
+        a_off[i] = row * ROWB; a_sw[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + fr;
+        b_off[j] = row * ROWB; b_sw[j] = (row >> 1) & 7;
+    }
+
+    issue(0, 0);
+    for (int ks = 0; ks < d.nk; ++ks) {
+        __syncthreads();   // stage ks landed (vmcnt(0) precedes the barrier); everyone is done reading the other stage
+        if (ks + 1 < d.nk) issue(ks + 1, (ks + 1) & 1);
+        const char* As = smem + (ks & 1) * A_BYTES;
+        const char* Bs = smem + 2 * A_BYTES + (ks & 1) * B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int ch = 2 * kk + fh;
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + a_off[i] + ((ch ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const int ohw = d.OH * d.OW;
+    if (d.out_f32) {
+        // fp32 NCHW output straight from the accumulators (generator head: Cout = 3, + bias, tanh)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = tile_n * BN + wn * WTN + j * 32 + fr;
+            if (col >= d.Cout) continue;
+            const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    const int m = tile_m * BM + row;
+                    if (m >= d.M) continue;
+                    const int n = m / hw_g, rem = m - n * hw_g;
+                    const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+                    float v = acc[i][j][e] + bv;
+                    if (d.relu) v = fmaxf(v, 0.f);
+                    if (d.act == 1) v = tanhf(v);
+                    else if (d.act == 2) v = 1.f / (1.f + __expf(-v));
+                    d.out_f32[((long)n * d.Cout + col) * ohw + (long)(oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox] = v;
+                }
+        }
+        return;
+    }
+
+    // fp16 NHWC output: transpose through LDS so that every lane stores 16 contiguous bytes
+    constexpr int CP = BN + 8;   // padded row (halves)
+    __syncthreads();             // all MFMA reads of the staging buffers are done
+    f16* Ct = (f16*)smem;
+    const bool relu_now = d.relu && !d.res;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + fr;
+        const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float v = acc[i][j][e] + bv;
+                if (relu_now) v = fmaxf(v, 0.f);
+                Ct[row * CP + col] = (f16)v;
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    constexpr int NCH = BM * CPR / 256;         // chunks per thread
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int id = c * 256 + tid;
+        const int row = id / CPR, c8 = id % CPR;
+        const int m = tile_m * BM + row;
+        const int col = tile_n * BN + c8 * 8;
+        if (m >= d.M || col >= d.Cout) continue;
+        const int n = m / hw_g, rem = m - n * hw_g;
+        const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+        const long off = ((long)n * ohw + (long)(oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox) * d.Cout + col;
+        f16x8 v = *(const f16x8*)(Ct + row * CP + c8 * 8);
+        if (d.res) {
+            const f16x8 rv = *(const f16x8*)(d.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)v[e] + (float)rv[e];
+                if (d.relu) t = fmaxf(t, 0.f);
+                v[e] = (f16)t;
+            }
+        }
+        *(f16x8*)(d.out + off) = v;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
+    const int ntm = (d.M + BM - 1) / BM, ntn = d.CoutPad / BN;
+    const int ntm8 = (ntm + 7) / 8 * 8;
+    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+    static_assert((size_t)BM * (BN + 8) * 2 <= 2 * (size_t)(BM + BN) * ROWB, "epilogue tile must fit the staging LDS");
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(256), lds, stream, d);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+}  // namespace
+
+int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream) {
+    GDT_REQUIRE(d.Cin >= 8 && (d.Cin & (d.Cin - 1)) == 0, "Cin must be a power of two >= 8");
+    GDT_REQUIRE((1 << d.lc8) * 8 == d.Cin, "lc8 mismatch");
+    GDT_REQUIRE(d.Kpad % BK == 0 && d.nk == d.Kpad / BK && d.nk >= 1, "Kpad must be a multiple of 64");
+    GDT_REQUIRE(d.ntaps * d.Cin <= d.Kpad, "Kpad too small");
+    GDT_REQUIRE(d.out_f32 || (d.Cout % 8 == 0), "fp16 NHWC output needs Cout % 8 == 0");
+    GDT_REQUIRE(d.M > 0 && d.zeros != nullptr, "empty launch");
+    const int bn = gdt_conv_bn(d.Cout);
+    GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
+    if (d.pad_reflect) {
+        const int pady = d.dy0 < 0 ? -d.dy0 : 0, padx = d.dx0 < 0 ? -d.dx0 : 0;
+        GDT_REQUIRE(pady < d.H && padx < d.W, "reflect padding needs pad < input size");
+    }
+    if (bn == 128) return launch_cfg<128, 128, 2, 2>(d, stream);
+    if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, stream);
+    return launch_cfg<128, 32, 4, 1>(d, stream);
+}

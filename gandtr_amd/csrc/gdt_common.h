@@ -1,0 +1,67 @@
+// Shared declarations for the gandtr HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (thread-local message, integer status; see include/gandtr_hip.h) ----
+void gdt_set_error(const std::string& msg);
+#define GDT_OK 0
+#define GDT_ERR_INVALID 1
+#define GDT_ERR_HIP 2
+#define GDT_ERR_WORKSPACE 3
+
+#define GDT_CHECK_HIP(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            gdt_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return GDT_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define GDT_REQUIRE(cond, msg)                                                                  \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            gdt_set_error(std::string("invalid argument: ") + msg + " [" #cond "]");            \
+            return GDT_ERR_INVALID;                                                             \
+        }                                                                                       \
+    } while (0)
+
+// ---- implicit-GEMM convolution launch descriptor ----
+// Activations are NHWC fp16; weights are packed [CoutPad][Kpad] fp16 with k = tap * Cin + c.
+// A "tap" t has input offset (dy, dx) = (dy0 + (t / TW) * dys, dx0 + (t % TW) * dxs); an output-grid position
+// (oy, ox) reads input pixel (oy * sy + dy, ox * sx + dx) and writes output pixel (oy * osy + ooy, ox * osx + oox).
+// That covers Conv2d (any k, stride 1/2, zero or reflect padding) and the four sub-pixel phases of
+// ConvTranspose2d(k3, s2, p1, op1).
+struct ConvLaunch {
+    const f16* in;        // [N][H][W][Cin]
+    const f16* w;         // [CoutPad][Kpad]
+    const float* bias;    // [CoutPad] or nullptr
+    const f16* res;       // residual, same layout as out, or nullptr
+    f16* out;             // [N][OH][OW][Cout]  (nullptr when out_f32 is used)
+    float* out_f32;       // [N][Cout][OH][OW] fp32 NCHW, or nullptr
+    float* stats;         // per-tile partial sums [M/BM tiles][2][Cout] for InstanceNorm, or nullptr
+    const f16* zeros;     // >= 16 B of zeros (source for padded / out-of-range chunks)
+    int N, H, W, Cin, lc8;        // lc8 = log2(Cin / 8)
+    int Cout, CoutPad, Kpad, nk;  // nk = Kpad / 64
+    int OHg, OWg, OH, OW;         // output grid of this launch, full output size
+    int sy, sx, osy, ooy, osx, oox;
+    int ntaps, TW, invTW, dy0, dys, dx0, dxs;
+    int pad_reflect;              // 0: zero padding, 1: reflect
+    int relu;                     // fused ReLU (after bias and residual)
+    int act;                      // out_f32 only: 0 none, 1 tanh, 2 sigmoid
+    int M;                        // N * OHg * OWg
+    int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
+};
+
+int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream);
+int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

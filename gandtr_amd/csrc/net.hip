@@ -1,0 +1,586 @@
+// Graph builder + executor behind the C ABI in include/gandtr_hip.h.
+//
+// The reference executes its models as nn.Sequential / nn.Module graphs (p2p_networks.py:313, imageretrievalnet.py:93,
+// hed.py:30-45).  Here the host mirror (gandtr_amd/, Python) describes the same layer graph once through gdt_net_*;
+// this file packs the weights (BatchNorm folded, fp16, [CoutPad][taps*Cin]), infers shapes per call, plans a
+// liveness-based workspace layout and launches the HIP kernels on the caller's stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/gandtr_hip.h"
+#include "aux_kernels.h"
+#include "gdt_common.h"
+
+static thread_local std::string g_last_error;
+void gdt_set_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+inline int next_pow2(int v) { int p = 8; while (p < v) p <<= 1; return p; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+enum OpKind { OP_INPUT, OP_CONV, OP_INORM, OP_MAXPOOL, OP_GEM, OP_OUT_NCHW, OP_HED };
+
+struct PackedPhase {
+    size_t w_off = 0;                 // byte offset in the device weight blob
+    int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
+    int ooy = 0, oox = 0;
+};
+
+struct Op {
+    OpKind kind;
+    int in = -1, res = -1, out = -1, slot = -1;
+    // conv
+    gdt_conv_desc cd{};
+    int cin_pad = 0, cout_pad = 0;
+    std::vector<PackedPhase> phases;
+    size_t bias_off = 0; bool has_bias = false;
+    // input
+    int in_c = 0; int perm[8]; float scale[8], shift[8];
+    // inorm
+    float eps = 1e-5f; int relu = 0;
+    // maxpool
+    int k = 0, s = 0, p = 0;
+    // gem
+    float gem_p = 3.f, eps_gem = 1e-6f, eps_l2 = 1e-6f;
+    // out_nchw
+    size_t tap_bias_off = 0; bool tap_has_bias = false;
+    // hed
+    int feats[5]; size_t score_w_off[5]; float score_b[5], fusion_w[5], fusion_b = 0.f; int sigmoid = 1;
+};
+
+struct Tensor { int C = 0; int H = 0, W = 0; int last_use = -1; size_t off = 0, bytes = 0; };
+
+// first-fit allocator with coalescing free list; "top" grows when nothing fits
+struct Arena {
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_;
+    size_t top = 0, peak = 0;
+    size_t alloc(size_t bytes) {
+        bytes = align_up(bytes);
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].size >= bytes) {
+                const size_t off = free_[i].off;
+                free_[i].off += bytes; free_[i].size -= bytes;
+                if (!free_[i].size) free_.erase(free_.begin() + i);
+                return off;
+            }
+        // extend the last free block if it touches the top
+        if (!free_.empty() && free_.back().off + free_.back().size == top) {
+            const size_t off = free_.back().off;
+            top = off + bytes; free_.pop_back();
+            peak = std::max(peak, top);
+            return off;
+        }
+        const size_t off = top;
+        top += bytes; peak = std::max(peak, top);
+        return off;
+    }
+    void release(size_t off, size_t bytes) {
+        bytes = align_up(bytes);
+        free_.push_back({off, bytes});
+        std::sort(free_.begin(), free_.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        std::vector<Blk> m;
+        for (auto& b : free_) {
+            if (!m.empty() && m.back().off + m.back().size == b.off) m.back().size += b.size;
+            else m.push_back(b);
+        }
+        free_.swap(m);
+    }
+};
+
+}  // namespace
+
+struct gdt_net {
+    std::vector<Op> ops;
+    std::vector<Tensor> tensors;
+    std::vector<int> out_ops;               // op index per external output slot
+    std::vector<unsigned char> host_blob;   // packed weights / biases staged on the host until finalize
+    char* dev_blob = nullptr;
+    size_t zeros_off = 0;
+    bool finalized = false;
+    int input_op = -1;
+
+    size_t blob_append(const void* data, size_t bytes) {
+        const size_t off = align_up(host_blob.size());
+        host_blob.resize(off + bytes);
+        if (data) memcpy(host_blob.data() + off, data, bytes);
+        else memset(host_blob.data() + off, 0, bytes);
+        return off;
+    }
+    int new_tensor(int C) { tensors.push_back(Tensor{C}); return (int)tensors.size() - 1; }
+};
+
+namespace {
+
+struct Step { int op; size_t aux_off[8]; };
+struct Plan { std::vector<Step> steps; size_t peak = 0; };
+
+int conv_out_dim(const gdt_conv_desc& c, int in, int k) {
+    if (c.transposed) return in * 2;
+    return (in + 2 * c.pad - k) / c.stride + 1;
+}
+
+// shape inference + workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
+int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
+    auto& T = net->tensors;
+    for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
+    // last uses
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        const Op& o = net->ops[i];
+        if (o.in >= 0) T[o.in].last_use = (int)i;
+        if (o.res >= 0) T[o.res].last_use = (int)i;
+        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = (int)i;
+    }
+    Arena arena;
+    plan.steps.clear();
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        const Op& o = net->ops[i];
+        Step st{}; st.op = (int)i;
+        auto set_out = [&](int h, int w) -> int {
+            GDT_REQUIRE(h > 0 && w > 0, "layer output would be empty for this input size");
+            Tensor& t = T[o.out];
+            t.H = h; t.W = w; t.bytes = (size_t)N * h * w * t.C * sizeof(f16);
+            t.off = arena.alloc(t.bytes);
+            return GDT_OK;
+        };
+        int rc = GDT_OK;
+        switch (o.kind) {
+            case OP_INPUT: rc = set_out(RH, RW); break;
+            case OP_CONV: {
+                const Tensor& ti = T[o.in];
+                const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh), ow = conv_out_dim(o.cd, ti.W, o.cd.kw);
+                if (o.cd.pad_reflect) GDT_REQUIRE(o.cd.pad < ti.H && o.cd.pad < ti.W, "reflection padding needs pad < input size");
+                if (o.out >= 0) rc = set_out(oh, ow);
+                if (o.res >= 0) GDT_REQUIRE(T[o.res].H == oh && T[o.res].W == ow, "residual shape mismatch");
+                break;
+            }
+            case OP_INORM: {
+                const Tensor& ti = T[o.in];
+                rc = set_out(ti.H, ti.W);
+                const int chunks = gdt_in_stats_chunks(ti.H * ti.W);
+                st.aux_off[0] = arena.alloc((size_t)N * chunks * 2 * ti.C * sizeof(float));
+                st.aux_off[1] = arena.alloc((size_t)N * ti.C * 2 * sizeof(float));
+                arena.release(st.aux_off[0], (size_t)N * chunks * 2 * ti.C * sizeof(float));
+                arena.release(st.aux_off[1], (size_t)N * ti.C * 2 * sizeof(float));
+                break;
+            }
+            case OP_MAXPOOL: {
+                const Tensor& ti = T[o.in];
+                rc = set_out((ti.H + 2 * o.p - o.k) / o.s + 1, (ti.W + 2 * o.p - o.k) / o.s + 1);
+                break;
+            }
+            case OP_GEM: {
+                const Tensor& ti = T[o.in];
+                st.aux_off[0] = arena.alloc((size_t)N * ti.C * sizeof(float));
+                arena.release(st.aux_off[0], (size_t)N * ti.C * sizeof(float));
+                break;
+            }
+            case OP_OUT_NCHW: break;
+            case OP_HED: {
+                size_t sz[5];
+                for (int k = 0; k < 5; ++k) {
+                    const Tensor& tf = T[o.feats[k]];
+                    sz[k] = (size_t)N * tf.H * tf.W * sizeof(float);
+                    st.aux_off[k] = arena.alloc(sz[k]);
+                }
+                for (int k = 0; k < 5; ++k) arena.release(st.aux_off[k], sz[k]);
+                break;
+            }
+        }
+        if (rc != GDT_OK) return rc;
+        // free dead inputs
+        auto maybe_free = [&](int t) {
+            if (t >= 0 && T[t].last_use == (int)i && T[t].bytes) { arena.release(T[t].off, T[t].bytes); T[t].last_use = -2; }
+        };
+        maybe_free(o.in); maybe_free(o.res);
+        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) maybe_free(o.feats[k]);
+        if (o.out >= 0 && T[o.out].last_use == -1) { arena.release(T[o.out].off, T[o.out].bytes); }   // never consumed
+        plan.steps.push_back(st);
+    }
+    plan.peak = arena.peak;
+    return GDT_OK;
+}
+
+// ---- host-side weight packing ----------------------------------------------------------------------------------
+void fold_bn(const gdt_conv_desc& cd, const float* bias, const float* g, const float* b, const float* m, const float* v,
+             std::vector<float>& scale, std::vector<float>& shift, bool& has_shift) {
+    scale.assign(cd.cout, 1.f); shift.assign(cd.cout, 0.f);
+    has_shift = bias != nullptr || g != nullptr;
+    for (int c = 0; c < cd.cout; ++c) {
+        float bs = bias ? bias[c] : 0.f;
+        if (g) {
+            const float s = g[c] / std::sqrt(v[c] + cd.bn_eps);
+            scale[c] = s; shift[c] = b[c] + (bs - m[c]) * s;
+        } else {
+            shift[c] = bs;
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* gdt_last_error(void) { return g_last_error.c_str(); }
+const char* gdt_version(void) { return "gandtr_hip 0.1 gfx950"; }
+
+int gdt_net_create(gdt_net** net) {
+    GDT_REQUIRE(net != nullptr, "net");
+    *net = new gdt_net();
+    std::vector<unsigned char> z(256, 0);
+    (*net)->zeros_off = (*net)->blob_append(z.data(), z.size());
+    return GDT_OK;
+}
+
+void gdt_net_destroy(gdt_net* net) {
+    if (!net) return;
+    if (net->dev_blob) (void)hipFree(net->dev_blob);
+    delete net;
+}
+
+int gdt_net_input(gdt_net* net, int channels, const int* perm, const float* scale, const float* shift, int* out_tensor) {
+    GDT_REQUIRE(net && !net->finalized && out_tensor, "net");
+    GDT_REQUIRE(net->input_op < 0, "only one external input per net");
+    GDT_REQUIRE(channels >= 1 && channels <= 8, "input channels must be 1..8");
+    Op o; o.kind = OP_INPUT; o.in_c = channels;
+    for (int c = 0; c < 8; ++c) {
+        o.perm[c] = (perm && c < channels) ? perm[c] : (c < channels ? c : 0);
+        GDT_REQUIRE(o.perm[c] >= 0 && o.perm[c] < channels, "channel permutation out of range");
+        o.scale[c] = (scale && c < channels) ? scale[c] : 1.f;
+        o.shift[c] = (shift && c < channels) ? shift[c] : 0.f;
+    }
+    o.out = net->new_tensor(8);
+    net->input_op = (int)net->ops.size();
+    net->ops.push_back(o);
+    *out_tensor = o.out;
+    return GDT_OK;
+}
+
+int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const float* weight, const float* bias,
+                 const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var,
+                 int residual_tensor, int* out_tensor) {
+    GDT_REQUIRE(net && !net->finalized && desc && weight && out_tensor, "net/desc/weight");
+    GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size(), "input tensor id");
+    GDT_REQUIRE(residual_tensor < (int)net->tensors.size(), "residual tensor id");
+    const gdt_conv_desc& cd = *desc;
+    GDT_REQUIRE(cd.cin >= 1 && cd.cout >= 1 && cd.kh >= 1 && cd.kw >= 1 && cd.kh * cd.kw <= 64, "conv geometry");
+    GDT_REQUIRE(cd.stride == 1 || cd.stride == 2, "stride must be 1 or 2");
+    GDT_REQUIRE((bn_gamma && bn_beta && bn_mean && bn_var) || (!bn_gamma && !bn_beta && !bn_mean && !bn_var), "BN vectors");
+    const int cin_pad = next_pow2(cd.cin);
+    GDT_REQUIRE(net->tensors[in_tensor].C == cin_pad, "input tensor channel count does not match conv cin");
+    if (cd.transposed) GDT_REQUIRE(cd.kh == 3 && cd.kw == 3 && cd.stride == 2 && cd.pad == 1 && !cd.pad_reflect,
+                                   "only ConvTranspose2d(k3,s2,p1,op1) is supported");
+    if (!cd.out_f32_nchw) GDT_REQUIRE(cd.cout % 8 == 0, "internal conv outputs need cout % 8 == 0");
+    if (residual_tensor >= 0) GDT_REQUIRE(net->tensors[residual_tensor].C == cd.cout && !cd.out_f32_nchw, "residual channels");
+
+    Op o; o.kind = OP_CONV; o.in = in_tensor; o.res = residual_tensor; o.cd = cd; o.cin_pad = cin_pad;
+    const int bn_tile = gdt_conv_bn(cd.cout);
+    o.cout_pad = (cd.cout + bn_tile - 1) / bn_tile * bn_tile;
+
+    std::vector<float> scale, shift; bool has_shift;
+    fold_bn(cd, bias, bn_gamma, bn_beta, bn_mean, bn_var, scale, shift, has_shift);
+    if (has_shift) {
+        std::vector<float> bp(o.cout_pad, 0.f);
+        std::copy(shift.begin(), shift.end(), bp.begin());
+        o.bias_off = net->blob_append(bp.data(), bp.size() * sizeof(float));
+        o.has_bias = true;
+    }
+
+    auto pack = [&](PackedPhase& ph, auto&& wget) {   // wget(cout, c, tap) -> float
+        const int K = ph.ntaps * cin_pad;
+        ph.Kpad = (K + 63) / 64 * 64;
+        std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f);
+        for (int co = 0; co < cd.cout; ++co)
+            for (int t = 0; t < ph.ntaps; ++t)
+                for (int c = 0; c < cd.cin; ++c)
+                    pk[(size_t)co * ph.Kpad + (size_t)t * cin_pad + c] = (f16)(wget(co, c, t) * scale[co]);
+        ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+    };
+
+    if (!cd.transposed) {
+        PackedPhase ph;
+        ph.ntaps = cd.kh * cd.kw; ph.TW = cd.kw; ph.dy0 = -cd.pad; ph.dys = 1; ph.dx0 = -cd.pad; ph.dxs = 1;
+        const int khw = cd.kh * cd.kw;
+        pack(ph, [&](int co, int c, int t) { return weight[((size_t)co * cd.cin + c) * khw + t]; });
+        o.phases.push_back(ph);
+    } else {
+        // o = 2i - 1 + k.  Even outputs (parity 0): k = 1, i = y.  Odd outputs: k = 0 (i = y + 1) and k = 2 (i = y).
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                PackedPhase ph;
+                const int th = py ? 2 : 1, tw = px ? 2 : 1;
+                ph.ntaps = th * tw; ph.TW = tw;
+                ph.dy0 = py ? 1 : 0; ph.dys = -1; ph.dx0 = px ? 1 : 0; ph.dxs = -1;
+                ph.ooy = py; ph.oox = px;
+                pack(ph, [&](int co, int c, int t) {
+                    const int ty = t / tw, tx = t % tw;
+                    const int ky = py ? (ty == 0 ? 0 : 2) : 1, kx = px ? (tx == 0 ? 0 : 2) : 1;
+                    return weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx];
+                });
+                o.phases.push_back(ph);
+            }
+    }
+    if (cd.out_f32_nchw) {
+        o.slot = (int)net->out_ops.size();
+        net->out_ops.push_back((int)net->ops.size());
+        *out_tensor = o.slot;
+    } else {
+        o.out = net->new_tensor(cd.cout);
+        *out_tensor = o.out;
+    }
+    net->ops.push_back(std::move(o));
+    return GDT_OK;
+}
+
+int gdt_net_instance_norm(gdt_net* net, int in_tensor, float eps, int relu, int residual_tensor, int* out_tensor) {
+    GDT_REQUIRE(net && !net->finalized && out_tensor, "net");
+    GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size() && residual_tensor < (int)net->tensors.size(), "tensor id");
+    const int C = net->tensors[in_tensor].C;
+    GDT_REQUIRE((C & (C - 1)) == 0 && C >= 8 && C <= 2048, "InstanceNorm needs a power-of-two channel count in [8, 2048]");
+    if (residual_tensor >= 0) GDT_REQUIRE(net->tensors[residual_tensor].C == C, "residual channels");
+    Op o; o.kind = OP_INORM; o.in = in_tensor; o.res = residual_tensor; o.eps = eps; o.relu = relu;
+    o.out = net->new_tensor(C);
+    net->ops.push_back(o);
+    *out_tensor = o.out;
+    return GDT_OK;
+}
+
+int gdt_net_maxpool(gdt_net* net, int in_tensor, int kernel, int stride, int pad, int* out_tensor) {
+    GDT_REQUIRE(net && !net->finalized && out_tensor, "net");
+    GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size(), "tensor id");
+    GDT_REQUIRE(kernel >= 1 && stride >= 1 && pad >= 0 && pad * 2 <= kernel, "maxpool geometry");
+    Op o; o.kind = OP_MAXPOOL; o.in = in_tensor; o.k = kernel; o.s = stride; o.p = pad;
+    o.out = net->new_tensor(net->tensors[in_tensor].C);
+    net->ops.push_back(o);
+    *out_tensor = o.out;
+    return GDT_OK;
+}
+
+int gdt_net_gem_l2n(gdt_net* net, int in_tensor, float p, float eps_gem, float eps_l2, int* out_slot) {
+    GDT_REQUIRE(net && !net->finalized && out_slot, "net");
+    GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size(), "tensor id");
+    GDT_REQUIRE(net->tensors[in_tensor].C % 64 == 0, "GeM needs channels % 64 == 0");
+    GDT_REQUIRE(p > 0.f, "GeM exponent must be positive");
+    Op o; o.kind = OP_GEM; o.in = in_tensor; o.gem_p = p; o.eps_gem = eps_gem; o.eps_l2 = eps_l2;
+    o.slot = (int)net->out_ops.size();
+    net->out_ops.push_back((int)net->ops.size());
+    net->ops.push_back(o);
+    *out_slot = o.slot;
+    return GDT_OK;
+}
+
+int gdt_net_output_nchw(gdt_net* net, int in_tensor, const float* bias, int* out_slot) {
+    GDT_REQUIRE(net && !net->finalized && out_slot, "net");
+    GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size(), "tensor id");
+    Op o; o.kind = OP_OUT_NCHW; o.in = in_tensor;
+    if (bias) { o.tap_bias_off = net->blob_append(bias, net->tensors[in_tensor].C * sizeof(float)); o.tap_has_bias = true; }
+    o.slot = (int)net->out_ops.size();
+    net->out_ops.push_back((int)net->ops.size());
+    net->ops.push_back(o);
+    *out_slot = o.slot;
+    return GDT_OK;
+}
+
+int gdt_net_hed_head(gdt_net* net, const int* feature_tensors, const float* const* score_w, const float* score_b,
+                     const float* fusion_w, float fusion_b, int sigmoid, int* out_slot) {
+    GDT_REQUIRE(net && !net->finalized && feature_tensors && score_w && score_b && fusion_w && out_slot, "net/args");
+    Op o; o.kind = OP_HED; o.sigmoid = sigmoid; o.fusion_b = fusion_b;
+    for (int k = 0; k < 5; ++k) {
+        GDT_REQUIRE(feature_tensors[k] >= 0 && feature_tensors[k] < (int)net->tensors.size(), "tensor id");
+        o.feats[k] = feature_tensors[k];
+        o.score_w_off[k] = net->blob_append(score_w[k], net->tensors[o.feats[k]].C * sizeof(float));
+        o.score_b[k] = score_b[k]; o.fusion_w[k] = fusion_w[k];
+    }
+    o.slot = (int)net->out_ops.size();
+    net->out_ops.push_back((int)net->ops.size());
+    net->ops.push_back(o);
+    *out_slot = o.slot;
+    return GDT_OK;
+}
+
+int gdt_net_finalize(gdt_net* net) {
+    GDT_REQUIRE(net && !net->finalized, "net");
+    GDT_REQUIRE(net->input_op == 0, "the first op must be gdt_net_input");
+    const size_t bytes = align_up(net->host_blob.size());
+    net->host_blob.resize(bytes);
+    GDT_CHECK_HIP(hipMalloc((void**)&net->dev_blob, bytes));
+    GDT_CHECK_HIP(hipMemcpy(net->dev_blob, net->host_blob.data(), bytes, hipMemcpyHostToDevice));
+    std::vector<unsigned char>().swap(net->host_blob);
+    net->finalized = true;
+    return GDT_OK;
+}
+
+int gdt_net_num_outputs(gdt_net* net) { return net ? (int)net->out_ops.size() : 0; }
+
+int gdt_net_output_shape(gdt_net* net, int slot, int n, int rh, int rw, int* dims, int* ndim) {
+    GDT_REQUIRE(net && dims && ndim && slot >= 0 && slot < (int)net->out_ops.size(), "slot");
+    Plan plan;
+    int rc = make_plan(net, n, rh, rw, plan);
+    if (rc != GDT_OK) return rc;
+    const Op& o = net->ops[net->out_ops[slot]];
+    const Tensor& ti = net->tensors[o.kind == OP_HED ? 0 : o.in];
+    switch (o.kind) {
+        case OP_CONV:
+            dims[0] = n; dims[1] = o.cd.cout; dims[2] = conv_out_dim(o.cd, ti.H, o.cd.kh); dims[3] = conv_out_dim(o.cd, ti.W, o.cd.kw);
+            *ndim = 4; break;
+        case OP_GEM: dims[0] = n; dims[1] = ti.C; *ndim = 2; break;
+        case OP_OUT_NCHW: dims[0] = n; dims[1] = ti.C; dims[2] = ti.H; dims[3] = ti.W; *ndim = 4; break;
+        case OP_HED: dims[0] = n; dims[1] = 1; dims[2] = rh; dims[3] = rw; *ndim = 4; break;
+        default: GDT_REQUIRE(false, "not an output op");
+    }
+    return GDT_OK;
+}
+
+int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes) {
+    GDT_REQUIRE(net && bytes && n >= 1 && rh >= 1 && rw >= 1, "geometry");
+    Plan plan;
+    int rc = make_plan(net, n, rh, rw, plan);
+    if (rc != GDT_OK) return rc;
+    *bytes = plan.peak + ALIGN;
+    return GDT_OK;
+}
+
+int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops) {
+    GDT_REQUIRE(net && flops, "net");
+    Plan plan;
+    int rc = make_plan(net, n, rh, rw, plan);
+    if (rc != GDT_OK) return rc;
+    double f = 0.0;
+    for (const Op& o : net->ops) {
+        if (o.kind == OP_CONV) {
+            const Tensor& ti = net->tensors[o.in];
+            if (o.cd.transposed)   // every input pixel meets every kernel tap once
+                f += 2.0 * n * ti.H * ti.W * (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw;
+            else
+                f += 2.0 * n * (double)conv_out_dim(o.cd, ti.H, o.cd.kh) * conv_out_dim(o.cd, ti.W, o.cd.kw) * o.cd.cin * o.cd.cout *
+                     o.cd.kh * o.cd.kw;
+        } else if (o.kind == OP_HED) {
+            for (int k = 0; k < 5; ++k) { const Tensor& tf = net->tensors[o.feats[k]]; f += 2.0 * n * tf.H * tf.W * tf.C; }
+            f += 2.0 * n * rh * rw * 5;
+        }
+    }
+    *flops = f;
+    return GDT_OK;
+}
+
+int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
+                    void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream) {
+    GDT_REQUIRE(net && net->finalized, "net must be finalized");
+    GDT_REQUIRE(x && n >= 1 && h >= 1 && w >= 1 && rh >= 1 && rw >= 1, "input geometry");
+    GDT_REQUIRE(n_outputs == (int)net->out_ops.size() && (outputs || n_outputs == 0), "output count");
+    GDT_REQUIRE((long)n * rh * rw < (1l << 31) && (long)n * h * w < (1l << 31), "N*H*W must stay below 2^31");
+    for (int i = 0; i < n_outputs; ++i) GDT_REQUIRE(outputs[i] != nullptr, "null output buffer");
+    Plan plan;
+    int rc = make_plan(net, n, rh, rw, plan);
+    if (rc != GDT_OK) return rc;
+    if (plan.peak + ALIGN > workspace_bytes || !workspace) {
+        gdt_set_error("workspace too small: need " + std::to_string(plan.peak + ALIGN) + " bytes, got " + std::to_string(workspace_bytes));
+        return GDT_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
+    auto& T = net->tensors;
+    auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };
+    const f16* zeros = (const f16*)(net->dev_blob + net->zeros_off);
+
+    for (const Step& stp : plan.steps) {
+        const Op& o = net->ops[stp.op];
+        switch (o.kind) {
+            case OP_INPUT: {
+                const int resize = (rh != h || rw != w) ? 1 : 0;
+                rc = gdt_k_pack_input(x, tptr(o.out), n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
+                break;
+            }
+            case OP_CONV: {
+                const Tensor& ti = T[o.in];
+                ConvLaunch d{};
+                d.in = tptr(o.in);
+                d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
+                d.res = o.res >= 0 ? tptr(o.res) : nullptr;
+                d.zeros = zeros;
+                d.N = n; d.H = ti.H; d.W = ti.W; d.Cin = o.cin_pad; d.lc8 = ilog2(o.cin_pad / 8);
+                d.Cout = o.cd.cout; d.CoutPad = o.cout_pad;
+                d.OH = conv_out_dim(o.cd, ti.H, o.cd.kh); d.OW = conv_out_dim(o.cd, ti.W, o.cd.kw);
+                if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
+                else { d.out = tptr(o.out); d.out_f32 = nullptr; }
+                d.pad_reflect = o.cd.pad_reflect; d.relu = o.cd.relu; d.act = o.cd.act;
+                for (const PackedPhase& ph : o.phases) {
+                    d.w = (const f16*)(net->dev_blob + ph.w_off);
+                    d.Kpad = ph.Kpad; d.nk = ph.Kpad / 64;
+                    d.ntaps = ph.ntaps; d.TW = ph.TW; d.invTW = (65536 + ph.TW - 1) / ph.TW;
+                    d.dy0 = ph.dy0; d.dys = ph.dys; d.dx0 = ph.dx0; d.dxs = ph.dxs;
+                    if (o.cd.transposed) {
+                        d.OHg = ti.H; d.OWg = ti.W; d.sy = d.sx = 1; d.osy = d.osx = 2; d.ooy = ph.ooy; d.oox = ph.oox;
+                    } else {
+                        d.OHg = d.OH; d.OWg = d.OW; d.sy = d.sx = o.cd.stride; d.osy = d.osx = 1; d.ooy = d.oox = 0;
+                    }
+                    d.M = n * d.OHg * d.OWg;
+                    rc = gdt_launch_conv(d, st);
+                    if (rc != GDT_OK) break;
+                }
+                break;
+            }
+            case OP_INORM: {
+                const Tensor& ti = T[o.in];
+                rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), (float*)(ws + stp.aux_off[0]),
+                                         (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, o.relu, st);
+                break;
+            }
+            case OP_MAXPOOL: {
+                const Tensor& ti = T[o.in]; const Tensor& to = T[o.out];
+                rc = gdt_k_maxpool(tptr(o.in), tptr(o.out), n, ti.H, ti.W, ti.C, to.H, to.W, o.k, o.s, o.p, st);
+                break;
+            }
+            case OP_GEM: {
+                const Tensor& ti = T[o.in];
+                rc = gdt_k_gem_l2n(tptr(o.in), (float*)(ws + stp.aux_off[0]), (float*)outputs[o.slot], n, ti.H * ti.W, ti.C, o.gem_p,
+                                   o.eps_gem, o.eps_l2, st);
+                break;
+            }
+            case OP_OUT_NCHW: {
+                const Tensor& ti = T[o.in];
+                rc = gdt_k_unpack_output(tptr(o.in), (float*)outputs[o.slot],
+                                         o.tap_has_bias ? (const float*)(net->dev_blob + o.tap_bias_off) : nullptr, n, ti.H * ti.W, ti.C, st);
+                break;
+            }
+            case OP_HED: {
+                const float* sc[5]; int hh[5], wwv[5];
+                for (int k = 0; k < 5 && rc == GDT_OK; ++k) {
+                    const Tensor& tf = T[o.feats[k]];
+                    float* s = (float*)(ws + stp.aux_off[k]);
+                    rc = gdt_k_hed_score(tptr(o.feats[k]), (const float*)(net->dev_blob + o.score_w_off[k]), o.score_b[k], s,
+                                         (long)n * tf.H * tf.W, tf.C, st);
+                    sc[k] = s; hh[k] = tf.H; wwv[k] = tf.W;
+                }
+                if (rc == GDT_OK) rc = gdt_k_hed_fuse(sc, hh, wwv, o.fusion_w, o.fusion_b, (float*)outputs[o.slot], n, rh, rw, o.sigmoid, st);
+                break;
+            }
+        }
+        if (rc != GDT_OK) return rc;
+    }
+    return GDT_OK;
+}
+
+int gdt_ms_aggregate(const float* x, float* y, int scales, int n, int d, float msp, void* stream) {
+    GDT_REQUIRE(x && y && scales >= 1 && n >= 1 && d >= 1, "ms_aggregate arguments");
+    return gdt_k_ms_aggregate(x, y, scales, n, d, msp, (hipStream_t)stream);
+}
+
+int gdt_whiten(const float* P, const float* m, const float* v, float* tmp, float* out, int n, int d, int dims, void* stream) {
+    GDT_REQUIRE(P && m && v && tmp && out && n >= 1 && d >= 1 && dims >= 1 && dims <= d, "whiten arguments");
+    return gdt_k_whiten(P, m, v, tmp, out, n, d, dims, (hipStream_t)stream);
+}
+
+int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream) {
+    GDT_REQUIRE(x && y && n >= 1 && d >= 1, "l2n arguments");
+    return gdt_k_l2n_rows(x, y, n, d, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+"""Host-side driver of the HIP graph executor (C ABI: include/gandtr_hip.h, binding: gandtr_amd/_hip.py).
+
+``HipNet`` mirrors the builder calls one-to-one; the ``build_*`` functions translate the reference's state dicts
+(names as produced by the reference modules, see gandtr_amd/tools/synth.py) into layer graphs:
+
+  build_generator   ResnetGenerator            mdir/components/model/network/p2p_networks.py:269-313, :454-506
+  build_embedder    ImageRetrievalNet (GeM)    mdir/external/cirtorch/networks/imageretrievalnet.py:101-123, :185-190
+  build_hed         HedInterpolation           mdir/components/model/network/hed.py:30-83
+
+PyTorch is used for device memory and streams only; no torch op runs on the data path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import ConvDesc
+
+
+def _f32(t):
+    """host fp32 contiguous numpy view of a tensor / array (None passes through)"""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        t = t.detach().to("cpu", torch.float32).contiguous().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class HipNet:
+    """One layer graph living on one GPU.  Not re-entrant (same rule as the C handle)."""
+
+    def __init__(self, device):
+        self.lib = _hip.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("HipNet needs a cuda (HIP) device, got %s" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.handle = ctypes.c_void_p()
+        _hip.check(self.lib.gdt_net_create(ctypes.byref(self.handle)))
+        self.in_channels = None
+        self._ws = None
+        self._finalized = False
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            self.lib.gdt_net_destroy(h)
+            self.handle = ctypes.c_void_p()
+
+    # ---- builder -------------------------------------------------------------------------------------------------
+    def input(self, channels, perm=None, scale=None, shift=None):
+        out = ctypes.c_int()
+        perm_a = (ctypes.c_int * channels)(*perm) if perm is not None else None
+        scale_a = (ctypes.c_float * channels)(*scale) if scale is not None else None
+        shift_a = (ctypes.c_float * channels)(*shift) if shift is not None else None
+        _hip.check(self.lib.gdt_net_input(self.handle, channels, perm_a, scale_a, shift_a, ctypes.byref(out)))
+        self.in_channels = channels
+        return out.value
+
+    def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, reflect=False, transposed=False, relu=False,
+             residual=-1, out_f32=False, act=0):
+        w = _f32(weight)
+        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        d = ConvDesc(cin, cout, w.shape[2], w.shape[3], stride, pad, int(reflect), int(transposed), int(relu),
+                     int(out_f32), act, 1e-5)
+        b = _f32(bias)
+        g = be = m = v = None
+        if bn is not None:
+            g, be, m, v = (_f32(t) for t in bn)
+        out = ctypes.c_int()
+        _hip.check(self.lib.gdt_net_conv(self.handle, x, ctypes.byref(d), _ptr(w), _ptr(b), _ptr(g), _ptr(be), _ptr(m),
+                                         _ptr(v), residual, ctypes.byref(out)))
+        return out.value
+
+    def instance_norm(self, x, relu=False, residual=-1, eps=1e-5):
+        out = ctypes.c_int()
+        _hip.check(self.lib.gdt_net_instance_norm(self.handle, x, eps, int(relu), residual, ctypes.byref(out)))
+        return out.value
+
+    def maxpool(self, x, kernel, stride, pad=0):
+        out = ctypes.c_int()
+        _hip.check(self.lib.gdt_net_maxpool(self.handle, x, kernel, stride, pad, ctypes.byref(out)))
+        return out.value
+
+    def gem_l2n(self, x, p, eps_gem=1e-6, eps_l2=1e-6):
+        out = ctypes.c_int()
+        _hip.check(self.lib.gdt_net_gem_l2n(self.handle, x, float(p), eps_gem, eps_l2, ctypes.byref(out)))
+        return out.value
+
+    def output_nchw(self, x, bias=None):
+        out = ctypes.c_int()
+        b = _f32(bias)
+        _hip.check(self.lib.gdt_net_output_nchw(self.handle, x, _ptr(b), ctypes.byref(out)))
+        return out.value
+
+    def hed_head(self, feats, score_w, score_b, fusion_w, fusion_b, sigmoid=True):
+        ws = [_f32(w).reshape(-1) for w in score_w]
+        wp = (ctypes.c_void_p * 5)(*[w.ctypes.data for w in ws])
+        out = ctypes.c_int()
+        _hip.check(self.lib.gdt_net_hed_head(self.handle, (ctypes.c_int * 5)(*feats), wp,
+                                             (ctypes.c_float * 5)(*[float(b) for b in score_b]),
+                                             (ctypes.c_float * 5)(*[float(w) for w in fusion_w]), float(fusion_b),
+                                             int(sigmoid), ctypes.byref(out)))
+        return out.value
+
+    def finalize(self):
+        with torch.cuda.device(self.device):
+            _hip.check(self.lib.gdt_net_finalize(self.handle))
+        self._finalized = True
+        return self
+
+    # ---- execution -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def resized_size(h, w, scale):
+        """Output size of F.interpolate(scale_factor=s): floor(float(in * s)) (torch/nn/functional.py)."""
+        if scale is None:
+            return h, w
+        return int(math.floor(float(h * scale))), int(math.floor(float(w * scale)))
+
+    def output_shapes(self, n, rh, rw):
+        shapes = []
+        dims, ndim = (ctypes.c_int * 4)(), ctypes.c_int()
+        for slot in range(self.lib.gdt_net_num_outputs(self.handle)):
+            _hip.check(self.lib.gdt_net_output_shape(self.handle, slot, n, rh, rw, dims, ctypes.byref(ndim)))
+            shapes.append(tuple(dims[i] for i in range(ndim.value)))
+        return shapes
+
+    def flops(self, n, rh, rw):
+        f = ctypes.c_double()
+        _hip.check(self.lib.gdt_net_flops(self.handle, n, rh, rw, ctypes.byref(f)))
+        return f.value
+
+    def workspace_bytes(self, n, rh, rw):
+        b = ctypes.c_size_t()
+        _hip.check(self.lib.gdt_net_workspace_bytes(self.handle, n, rh, rw, ctypes.byref(b)))
+        return b.value
+
+    def forward(self, x, scale=None):
+        """x: fp32 NCHW tensor on this net's device.  ``scale``: optional F.interpolate scale_factor applied to the
+        input inside the pack kernel.  Returns the list of external outputs (torch tensors on the device)."""
+        if not self._finalized:
+            raise RuntimeError("HipNet.forward before finalize()")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError("expected an N x %s x H x W input, got %s" % (self.in_channels, tuple(x.shape)))
+        if x.device != self.device:
+            x = x.to(self.device)
+        x = x.contiguous().float()
+        n, _, h, w = x.shape
+        rh, rw = self.resized_size(h, w, scale)
+        rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
+        with torch.cuda.device(x.device):
+            need = self.workspace_bytes(n, rh, rw)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.output_shapes(n, rh, rw)]
+            optrs = (ctypes.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _hip.check(self.lib.gdt_net_forward(self.handle, x.data_ptr(), n, h, w, rh, rw, rscale, optrs, len(outs),
+                                                self._ws.data_ptr(), self._ws.numel(), stream))
+        return outs
+
+
+# ======================================================================================================= builders
+
+def _bn(sd, p):
+    return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
+
+
+def generator_layout(sd):
+    """(norm, ngf, n_blocks, in_nc, out_nc) recovered from state-dict keys: BatchNorm iff ``model.2.running_mean`` is
+    present (use_bias rule p2p_networks.py:264-267)."""
+    norm = "batch" if "model.2.running_mean" in sd else "instance"
+    n_blocks = sum(1 for k in sd if k.endswith(".conv_block.1.weight"))
+    w0 = sd["model.1.weight"]
+    last = 10 + n_blocks + 6 + 1
+    return norm, w0.shape[0], n_blocks, w0.shape[1], sd["model.%d.weight" % last].shape[0]
+
+
+def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None):
+    """ResnetGenerator as a HIP graph.  External outputs: [generator output] + one per requested tap (in ``taps``
+    order).  Taps follow the reference's nn.Sequential indices (p2p_networks.py:316-334); a norm-layer tap aliases the
+    post-ReLU tensor because the reference's ReLUs are in-place (:272).  Tap 0 / the second reflection pad are not
+    materialised on the device (padding is resolved inside the conv loader) and are not available."""
+    norm, ngf, n_blocks, in_nc, out_nc = generator_layout(sd)
+    inorm = norm == "instance"
+    net = HipNet(device)
+    tap_slots = {}
+
+    def tap(idx, t, bias=None):
+        if idx in taps and idx not in tap_slots:
+            tap_slots[idx] = net.output_nchw(t, bias)
+
+    def conv_norm_relu(x, key, nkey, idx, relu=True, residual=-1, **kw):
+        """conv -> norm -> (ReLU) (+ residual).  InstanceNorm: bias-free conv (the bias cancels in the norm) + separate
+        norm kernels; BatchNorm: folded into the conv epilogue."""
+        if inorm:
+            raw = net.conv(x, sd[key + ".weight"], None, **kw)
+            if idx is not None:
+                tap(idx, raw, sd.get(key + ".bias"))
+            return net.instance_norm(raw, relu=relu, residual=residual)
+        if idx is not None and idx in taps:   # raw conv output requested: unfused variant
+            raw = net.conv(x, sd[key + ".weight"], sd.get(key + ".bias"), **kw)
+            tap(idx, raw)
+        return net.conv(x, sd[key + ".weight"], sd.get(key + ".bias"), bn=_bn(sd, nkey), relu=relu, residual=residual, **kw)
+
+    if in_affine is not None:
+        x = net.input(in_nc, scale=in_affine[0], shift=in_affine[1])
+    else:
+        x = net.input(in_nc)
+    h = conv_norm_relu(x, "model.1", "model.2", 1, pad=3, reflect=True)
+    tap(2, h); tap(3, h)
+    i = 4
+    for _ in range(2):
+        h = conv_norm_relu(h, "model.%d" % i, "model.%d" % (i + 1), i, stride=2, pad=1)
+        tap(i + 1, h); tap(i + 2, h)
+        i += 3
+    for _ in range(n_blocks):
+        p = "model.%d.conv_block." % i
+        r = conv_norm_relu(h, p + "1", p + "2", None, pad=1, reflect=True)
+        h = conv_norm_relu(r, p + "5", p + "6", None, relu=False, residual=h, pad=1, reflect=True)
+        tap(i, h)
+        i += 1
+    for _ in range(2):
+        h = conv_norm_relu(h, "model.%d" % i, "model.%d" % (i + 1), i, transposed=True, stride=2, pad=1)
+        tap(i + 1, h); tap(i + 2, h)
+        i += 3
+    head = "model.%d" % (i + 1)
+    if (i + 1) in taps and not pre_tanh:
+        tap_slots[i + 1] = net.conv(h, sd[head + ".weight"], sd[head + ".bias"], pad=3, reflect=True, out_f32=True, act=0)
+    out = net.conv(h, sd[head + ".weight"], sd[head + ".bias"], pad=3, reflect=True, out_f32=True, act=0 if pre_tanh else 1)
+    if (i + 2) in taps:
+        tap_slots[i + 2] = out
+    net.finalize()
+    net.out_slot = out
+    net.tap_slots = tap_slots
+    return net
+
+
+VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]
+RESNET101_BLOCKS = (3, 4, 23, 3)
+
+
+def _vgg16_trunk(net, x, sd, prefix="features."):
+    i = 0
+    for v in VGG16_CFG:
+        if v == "M":
+            x = net.maxpool(x, 2, 2)
+            i += 1
+        else:
+            x = net.conv(x, sd["%s%d.weight" % (prefix, i)], sd["%s%d.bias" % (prefix, i)], pad=1, relu=True)
+            i += 2
+    return x
+
+
+def _resnet_trunk(net, x, sd, prefix="features."):
+    blocks = []
+    for li in range(4):
+        nb = 0
+        while "%s%d.%d.conv1.weight" % (prefix, 4 + li, nb) in sd:
+            nb += 1
+        blocks.append(nb)
+    x = net.conv(x, sd[prefix + "0.weight"], None, bn=_bn(sd, prefix + "1"), stride=2, pad=3, relu=True)
+    x = net.maxpool(x, 3, 2, 1)
+    for li, nb in enumerate(blocks):
+        for b in range(nb):
+            p = "%s%d.%d." % (prefix, 4 + li, b)
+            stride = 2 if (b == 0 and li > 0) else 1
+            idt = x
+            if b == 0:
+                idt = net.conv(x, sd[p + "downsample.0.weight"], None, bn=_bn(sd, p + "downsample.1"), stride=stride)
+            o = net.conv(x, sd[p + "conv1.weight"], None, bn=_bn(sd, p + "bn1"), relu=True)
+            o = net.conv(o, sd[p + "conv2.weight"], None, bn=_bn(sd, p + "bn2"), stride=stride, pad=1, relu=True)
+            x = net.conv(o, sd[p + "conv3.weight"], None, bn=_bn(sd, p + "bn3"), relu=True, residual=idt)
+    return x
+
+
+def embedder_arch(sd):
+    """'vgg16' or 'resnet101'-style trunk, recognised from the state-dict keys (imageretrievalnet.py:185-190)."""
+    return "resnet" if "features.4.0.conv1.weight" in sd else "vgg16"
+
+
+def build_embedder(sd, device, in_affine=None, feature_tap=False):
+    """GeM embedder (ImageRetrievalNet.forward with lwhiten=None, whiten=None).  External output 0: descriptors as a
+    row-major [N][D] fp32 matrix (the reference returns its transpose view, D x N)."""
+    net = HipNet(device)
+    x = net.input(3, scale=in_affine[0], shift=in_affine[1]) if in_affine is not None else net.input(3)
+    f = _resnet_trunk(net, x, sd) if embedder_arch(sd) == "resnet" else _vgg16_trunk(net, x, sd)
+    net.out_slot = net.gem_l2n(f, float(sd["pool.p"].reshape(-1)[0]))
+    net.feature_slot = net.output_nchw(f) if feature_tap else None
+    net.finalize()
+    return net
+
+
+HED_BLOCKS = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
+
+
+def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True):
+    """HedInterpolation.forward (hed.py:60-83); ``perm``/``in_affine`` fold the RgbToBgrPre + MeanStdPre wrappers
+    (wrapper.py:351-364, :182-194) into the input pack kernel."""
+    net = HipNet(device)
+    x = net.input(3, perm=perm, scale=None if in_affine is None else in_affine[0],
+                  shift=None if in_affine is None else in_affine[1])
+    feats = []
+    for bi in range(5):
+        off = 0
+        if bi > 0:
+            x = net.maxpool(x, 2, 2)
+            off = 1
+        ci = 0
+        while "vgg%d.%d.weight" % (bi + 1, off + 2 * ci) in sd:
+            k = "vgg%d.%d" % (bi + 1, off + 2 * ci)
+            x = net.conv(x, sd[k + ".weight"], sd[k + ".bias"], pad=1, relu=True)
+            ci += 1
+        feats.append(x)
+    net.out_slot = net.hed_head(
+        feats, [sd["score%d.weight" % (k + 1)] for k in range(5)], [float(sd["score%d.bias" % (k + 1)]) for k in range(5)],
+        [float(v) for v in sd["fusion.0.weight"].reshape(-1)], float(sd["fusion.0.bias"]), sigmoid)
+    net.finalize()
+    return net
+
+
+# ======================================================================================== stand-alone descriptor ops
+
+def ms_aggregate(x, msp):
+    """x: [S][N][D] fp32 cuda -> [N][D]  (wrapper.py:236-245, batched)."""
+    lib = _hip.load()
+    x = x.contiguous().float()
+    s, n, d = x.shape
+    y = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _hip.check(lib.gdt_ms_aggregate(x.data_ptr(), y.data_ptr(), s, n, d, float(msp),
+                                        torch.cuda.current_stream(x.device).cuda_stream))
+    return y
+
+
+def whiten(v, P, m, dims=None):
+    """v: [N][D], P: [D][D], m: [D] or [D][1] (fp32 cuda) -> [N][dims]  (wrapper.py:320-322, batched)."""
+    lib = _hip.load()
+    v = v.contiguous().float()
+    P = P.contiguous().float()
+    m = m.contiguous().float().reshape(-1)
+    n, d = v.shape
+    dims = int(dims or P.shape[0])
+    tmp = torch.empty((n, dims), dtype=torch.float32, device=v.device)
+    out = torch.empty((n, dims), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _hip.check(lib.gdt_whiten(P.data_ptr(), m.data_ptr(), v.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, d, dims,
+                                  torch.cuda.current_stream(v.device).cuda_stream))
+    return out
+
+
+def l2n_rows(x, eps=1e-6):
+    lib = _hip.load()
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _hip.check(lib.gdt_l2n_rows(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], eps,
+                                    torch.cuda.current_stream(x.device).cuda_stream))
+    return y

@@ -1,0 +1,134 @@
+/* gandtr_hip.h -- C ABI of libgandtr_hip.so, the MI355X (gfx950) implementation of the gandtr inference hot path.
+ *
+ * The reference (mohwald/gandtr) is pure Python on torch and has NO native boundary of its own; every entry point
+ * below therefore replaces a *Python-level* call site of the reference, cited as file:line relative to the reference
+ * root.  The host side (gandtr_amd/, Python) binds these symbols with ctypes (gandtr_amd/_hip.py) -- see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default stream.
+ *   - every function returns 0 (GDT_OK) or a positive status; gdt_last_error() returns the thread-local message.
+ *     The Python binding re-raises GDT_ERR_INVALID as ValueError / AssertionError like the reference's own checks
+ *     (SURVEY.md section 8b "Error conventions").
+ *   - a gdt_net is bound to the device that was current at gdt_net_finalize() and is not re-entrant.
+ *   - ownership: the caller (PyTorch) owns all input / output / workspace buffers; a net owns its packed weights.
+ *   - external images are fp32 NCHW (the reference's layout); internal activations are fp16 NHWC.
+ */
+#ifndef GANDTR_HIP_H
+#define GANDTR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDT_OK 0
+#define GDT_ERR_INVALID 1   /* bad argument / unsupported shape   */
+#define GDT_ERR_HIP 2       /* a HIP runtime call failed          */
+#define GDT_ERR_WORKSPACE 3 /* workspace too small                */
+
+const char* gdt_last_error(void);
+/* library self-description: "gandtr_hip <version> gfx950" */
+const char* gdt_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Network graph builder + executor.
+ * Replaces nn.Sequential / nn.Module.forward execution of
+ *   ResnetGenerator.forward          mdir/components/model/network/p2p_networks.py:315-337 (layers :269-313, :454-506)
+ *   ImageRetrievalNet.forward        mdir/external/cirtorch/networks/imageretrievalnet.py:101-123
+ *   HedInterpolation.forward         mdir/components/model/network/hed.py:60-83
+ * Tensors are referred to by the integer ids the builder returns.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct gdt_net gdt_net;
+
+int gdt_net_create(gdt_net** net);
+void gdt_net_destroy(gdt_net* net);
+
+/* External fp32 NCHW image input with C <= 8 channels (packed to fp16 NHWC8 on entry).  Optional channel permutation
+ * (RgbToBgrPre, mdir/components/data/wrapper.py:351-364) and per-channel affine y = x*scale + shift
+ * (MeanStdPost/Pre._adapt, wrapper.py:172-175); pass NULL for identity.  A bilinear resize
+ * (F.interpolate(scale_factor=s, mode='bilinear', align_corners=False), wrapper.py:225) is selected per forward call. */
+int gdt_net_input(gdt_net* net, int channels, const int* perm, const float* scale, const float* shift, int* out_tensor);
+
+typedef struct gdt_conv_desc {
+    int cin, cout;        /* logical channel counts (cin is padded to a power of two >= 8 internally)            */
+    int kh, kw;           /* kernel size (1, 3 or 7 on the hot path)                                               */
+    int stride;           /* 1 or 2                                                                                */
+    int pad;              /* padding on every side                                                                 */
+    int pad_reflect;      /* 0: zeros (Conv2d padding=p), 1: nn.ReflectionPad2d(p) in front of the conv            */
+    int transposed;       /* 1: nn.ConvTranspose2d(k3, s2, p1, output_padding 1)  (p2p_networks.py:295-298)        */
+    int relu;             /* fuse nn.ReLU after bias (+BN) (+residual)                                             */
+    int out_f32_nchw;     /* 1: result is an EXTERNAL fp32 NCHW output (generator head), 0: internal fp16 tensor   */
+    int act;              /* external output only: 0 none, 1 tanh (p2p_networks.py:311), 2 sigmoid                 */
+    float bn_eps;         /* eps of the folded BatchNorm2d (1e-5)                                                  */
+} gdt_conv_desc;
+
+/* Conv2d / ConvTranspose2d with host fp32 weights in torch layout ([cout][cin][kh][kw], transposed: [cin][cout][kh][kw]).
+ * bias and the four BatchNorm2d(eval) vectors may be NULL; BN is folded into the packed weights (get_norm_layer "batch",
+ * p2p_networks.py:27; torchvision ResNet BN).  residual_tensor >= 0 adds that tensor before the ReLU
+ * (ResnetBlock.forward p2p_networks.py:505; torchvision Bottleneck).  out_tensor receives the new tensor id, or the
+ * external output slot index when out_f32_nchw = 1. */
+int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const float* weight, const float* bias,
+                 const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var,
+                 int residual_tensor, int* out_tensor);
+
+/* nn.InstanceNorm2d(affine=False, eps) (+ fused ReLU) (+ fused residual add AFTER the norm): p2p_networks.py:29,:272,:505 */
+int gdt_net_instance_norm(gdt_net* net, int in_tensor, float eps, int relu, int residual_tensor, int* out_tensor);
+
+/* nn.MaxPool2d(kernel, stride, padding), floor mode */
+int gdt_net_maxpool(gdt_net* net, int in_tensor, int kernel, int stride, int pad, int* out_tensor);
+
+/* l2n(gem(x, p, eps_gem), eps_l2): cirtorch layers/functional.py:21-22,:130-131.  External output: fp32 [N][D]
+ * row-major, i.e. the memory the reference's `o.permute(1,0)` view aliases (imageretrievalnet.py:123). */
+int gdt_net_gem_l2n(gdt_net* net, int in_tensor, float p, float eps_gem, float eps_l2, int* out_slot);
+
+/* Feature tap: internal fp16 NHWC tensor -> external fp32 NCHW (+ optional per-channel bias), p2p_networks.py:316-334 */
+int gdt_net_output_nchw(gdt_net* net, int in_tensor, const float* bias, int* out_slot);
+
+/* HED head (hed.py:67-83): five 1x1 score convs (weights score_w[k] of length channels of tensor k, bias score_b[k]),
+ * bilinear upsampling of each score map to the network input size, 1x1 fusion (fusion_w[5], fusion_b), sigmoid.
+ * External output fp32 [N][1][H][W]. */
+int gdt_net_hed_head(gdt_net* net, const int* feature_tensors, const float* const* score_w, const float* score_b,
+                     const float* fusion_w, float fusion_b, int sigmoid, int* out_slot);
+
+/* Upload packed weights to the current device.  No more ops can be added afterwards. */
+int gdt_net_finalize(gdt_net* net);
+
+/* Shape of an external output for a given input geometry.  (rh, rw) is the resized input size (== h, w without
+ * resize).  dims receives up to 4 ints, ndim their count. */
+int gdt_net_output_shape(gdt_net* net, int slot, int n, int rh, int rw, int* dims, int* ndim);
+int gdt_net_num_outputs(gdt_net* net);
+
+/* Bytes of caller-provided scratch needed by gdt_net_forward for this geometry. */
+int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes);
+
+/* Run the graph.  x: device fp32 [n][c][h][w].  If (rh, rw) != (h, w) the input is bilinearly resized with torch's
+ * scale_factor semantics, rscale = (float)(1.0 / scale_factor).  outputs[i] is the device buffer of external slot i. */
+int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
+                    void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Algorithmic conv FLOPs (2*MACs, real channel counts, bias/norm/activation excluded) of one forward at this geometry:
+ * the numerator of bench.py's roofline.achieved. */
+int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Stand-alone descriptor ops (device fp32 buffers)
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* CirMultiscaleAggregation.aggregate_tensor (wrapper.py:236-245), batched over images: x [S][N][D] -> y [N][D],
+ * y = (mean_s x^msp)^(1/msp), then y /= ||y||_2 (no eps). */
+int gdt_ms_aggregate(const float* x, float* y, int scales, int n, int d, float msp, void* stream);
+
+/* CirtorchWhiten.postprocess (wrapper.py:320-322), batched: v [N][D], P [D][D] row-major, m [D] -> out [N][dims],
+ * out = P[:dims] (v - m) / (||.||_2 + 1e-6).  tmp: [N][dims] scratch. */
+int gdt_whiten(const float* P, const float* m, const float* v, float* tmp, float* out, int n, int d, int dims, void* stream);
+
+/* x / (||x||_2 + eps) over rows of a [N][D] matrix (cirtorch layers/functional.py:130-131) */
+int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANDTR_HIP_H */

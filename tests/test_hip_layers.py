@@ -1,0 +1,142 @@
+"""GPU parity of single layers / small graphs built through the C ABI against torch fp32 CPU ops (the oracle's
+building blocks).  Tolerances: the HIP path stores activations in fp16 with fp32 accumulation, so a single layer is
+held to 2e-3 of the reference's max magnitude (fp16 rounding of inputs, weights and outputs: 3 x 2^-11)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gandtr_amd.tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _run_single_conv(dev, cin, cout, k, stride, pad, reflect, transposed, relu, bn, n=2, h=20, w=28, seed=0):
+    from gandtr_amd.engine import HipNet
+    g = lambda name, shape, std=1.0: synth._normal(seed, name, shape, std)
+    net = HipNet(dev)
+    t = net.input(3)
+    # lift 3 -> cin channels with a 1x1 conv so that the layer under test sees a real multi-channel fp16 input
+    w0 = g("w0", (cin, 3, 1, 1), 0.7)
+    t = net.conv(t, w0)
+    tap_in = net.output_nchw(t)
+    wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    wt = g("w", wshape, math.sqrt(2.0 / (cin * k * k)))
+    bias = g("b", (cout,), 0.2)
+    bnp = None
+    if bn:
+        bnp = (synth._uniform(seed, "g", (cout,), 0.5, 1.5), g("be", (cout,), 0.2), g("m", (cout,), 0.2),
+               synth._uniform(seed, "v", (cout,), 0.5, 1.5))
+    out = net.conv(t, wt, bias, bn=bnp, stride=stride, pad=pad, reflect=reflect, transposed=transposed, relu=relu)
+    tap_out = net.output_nchw(out)
+    net.finalize()
+    x = synth.synth_input(seed + 1, (n, 3, h, w))
+    outs = net.forward(x.to(dev))
+    xin = outs[tap_in].cpu()      # the fp16-rounded activations the layer really consumed
+    wq = wt.half().float()
+    if transposed:
+        ref = F.conv_transpose2d(xin, wq, bias, stride=2, padding=1, output_padding=1)
+    else:
+        xi = F.pad(xin, (pad,) * 4, mode="reflect") if reflect else xin
+        ref = F.conv2d(xi, wq, bias, stride=stride, padding=0 if reflect else pad)
+    if bn:
+        # BN is folded into the fp16 weights on the device, so fold it the same way for a tight comparison
+        ref = F.batch_norm(ref, bnp[2], bnp[3], bnp[0], bnp[1], training=False, eps=1e-5)
+    if relu:
+        ref = F.relu(ref)
+    return outs[tap_out].cpu(), ref
+
+
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, k, stride, pad, reflect, transposed, relu, bn
+    (8, 8, 3, 1, 1, True, False, False, False),
+    (16, 32, 3, 1, 1, False, False, True, False),
+    (64, 64, 3, 1, 1, True, False, True, True),
+    (64, 128, 3, 2, 1, False, False, True, False),
+    (128, 256, 3, 2, 1, False, False, False, True),
+    (256, 256, 3, 1, 1, True, False, False, False),
+    (256, 128, 3, 2, 1, False, True, True, False),
+    (32, 16, 3, 2, 1, False, True, False, True),
+    (64, 256, 1, 1, 0, False, False, True, True),
+    (256, 64, 1, 2, 0, False, False, False, True),
+    (8, 64, 7, 1, 3, True, False, True, False),
+    (8, 64, 7, 2, 3, False, False, True, True),
+    (512, 512, 3, 1, 1, False, False, True, False),
+])
+def test_conv_layer(cuda_device, cfg):
+    cin, cout, k, stride, pad, reflect, transposed, relu, bn = cfg
+    got, ref = _run_single_conv(cuda_device, cin, cout, k, stride, pad, reflect, transposed, relu, bn)
+    assert got.shape == ref.shape
+    tol = 2e-3 if not bn else 4e-3     # folded BN scales the fp16 weight rounding
+    assert _rel(got, ref) < tol, (cfg, _rel(got, ref))
+
+
+def test_conv_ragged_tail(cuda_device):
+    """M not a multiple of the 128-row tile and odd spatial sizes."""
+    got, ref = _run_single_conv(cuda_device, 64, 64, 3, 1, 1, True, False, True, False, n=3, h=13, w=17)
+    assert _rel(got, ref) < 2e-3
+    got, ref = _run_single_conv(cuda_device, 64, 128, 3, 2, 1, False, False, False, False, n=1, h=9, w=11)
+    assert _rel(got, ref) < 2e-3
+
+
+def test_instance_norm_relu_residual(cuda_device):
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "wa", (32, 3, 1, 1), 0.7))
+    b = net.conv(t, synth._normal(0, "wb", (32, 3, 1, 1), 0.7))
+    ta, tb = net.output_nchw(a), net.output_nchw(b)
+    o1 = net.output_nchw(net.instance_norm(a, relu=True))
+    o2 = net.output_nchw(net.instance_norm(a, relu=False, residual=b))
+    net.finalize()
+    x = synth.synth_input(3, (2, 3, 40, 24))
+    outs = [o.cpu() for o in net.forward(x.to(cuda_device))]
+    A, B = outs[ta], outs[tb]
+    assert _rel(outs[o1], F.relu(F.instance_norm(A, eps=1e-5))) < 1.5e-3
+    assert _rel(outs[o2], F.instance_norm(A, eps=1e-5) + B) < 1.5e-3
+
+
+@pytest.mark.parametrize("k,s,p", [(2, 2, 0), (3, 2, 1)])
+def test_maxpool(cuda_device, k, s, p):
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "wa", (16, 3, 1, 1), 0.7))
+    ta = net.output_nchw(a)
+    to = net.output_nchw(net.maxpool(a, k, s, p))
+    net.finalize()
+    x = synth.synth_input(4, (2, 3, 21, 30))
+    outs = [o.cpu() for o in net.forward(x.to(cuda_device))]
+    assert torch.equal(outs[to], F.max_pool2d(outs[ta], k, s, p))    # max of fp16 values is exact
+
+
+@pytest.mark.parametrize("scale", [None, 1.0, 1.0 / math.sqrt(2), 0.5, math.sqrt(2)])
+def test_input_pack_and_resize(cuda_device, scale):
+    """F.interpolate(scale_factor=s, bilinear, align_corners=False) fused into the input pack kernel (wrapper.py:225)."""
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    o = net.output_nchw(t)
+    net.finalize()
+    x = synth.synth_input(5, (2, 3, 40, 56))
+    got = net.forward(x.to(cuda_device), scale=scale)[o].cpu()[:, :3]
+    ref = x if scale is None else F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 4e-3      # fp16 storage of values up to ~4
+
+
+def test_input_perm_affine(cuda_device):
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3, perm=[2, 1, 0], scale=[0.5, 2.0, 1.0], shift=[0.1, -0.2, 0.3])
+    o = net.output_nchw(t)
+    net.finalize()
+    x = synth.synth_input(6, (1, 3, 8, 8))
+    got = net.forward(x.to(cuda_device))[o].cpu()[:, :3]
+    ref = x[:, [2, 1, 0]] * torch.tensor([0.5, 2.0, 1.0])[None, :, None, None] + torch.tensor([0.1, -0.2, 0.3])[None, :, None, None]
+    assert float((got - ref).abs().max()) < 4e-3

@@ -1,0 +1,115 @@
+"""GPU parity of the whole hot path (through the C ABI) against the CPU oracle on the same seeded inputs and
+synthesised weights.  Gates: generator taps/outputs max|d|/max|ref| <= 1e-3 (pre-tanh, D6);
+descriptors ||d||_inf <= 1e-3 and cosine >= 0.9999."""
+import math
+
+import pytest
+import torch
+
+from gandtr_amd.tools import synth
+from oracle import gandtr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _cos(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_tiny_all_taps(cuda_device, norm):
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, ngf=8, n_blocks=2)
+    x = synth.synth_input(1, (2, 3, 32, 32), 1.0)
+    taps = tuple(i for i in range(1, 21) if i != 18)
+    ref, feats = O.resnet_generator(x, sd, norm, 2, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps)
+    outs = net.forward(x.to(cuda_device))
+    assert _rel(outs[net.out_slot].cpu(), ref) < 1e-3
+    for t in taps:
+        got = outs[net.tap_slots[t]].cpu()
+        assert got.shape == feats[t].shape, t
+        assert _rel(got, feats[t]) < 2e-3, (t, _rel(got, feats[t]))
+
+
+@pytest.mark.parametrize("norm,gain", [("instance", 0.02), ("instance", 0.2), ("batch", None)])
+def test_generator_full_pre_tanh(cuda_device, norm, gain):
+    """Full-size ResnetGenerator (ngf 64, 9 blocks) on 2x3x256x256; pre-tanh output (tap 26) and block taps."""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, gain=gain or 0.02)
+    x = synth.synth_input(2, (2, 3, 256, 256), 1.0)
+    taps = (9, 14, 18, 24, 26)
+    ref, feats = O.resnet_generator(x, sd, norm, 9, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps)
+    outs = net.forward(x.to(cuda_device))
+    for t in taps:
+        r = _rel(outs[net.tap_slots[t]].cpu(), feats[t])
+        assert r < 1e-3, (t, r)
+    assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("arch", ["vgg16", "resnet101"])
+def test_embedder_small(cuda_device, arch):
+    from gandtr_amd.engine import build_embedder
+    sd = synth.vgg16_state(0, p=3.0) if arch == "vgg16" else synth.resnet101_state(0, p=2.37)
+    x = synth.synth_input(3, (2, 3, 160, 192))
+    ref = O.image_retrieval_forward(x, sd, arch).t().contiguous()       # N x D
+    net = build_embedder(sd, cuda_device)
+    got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 1e-3
+    for i in range(ref.shape[0]):
+        assert _cos(got[i], ref[i]) > 0.9999
+
+
+def test_embedder_multiscale_whiten(cuda_device):
+    """Hub gem_*(pretrained=True) call path: pyramid -> per-scale forward -> aggregate (msp = p) -> whiten."""
+    from gandtr_amd import engine
+    sd = synth.resnet101_state(0, p=3.0)
+    lw = synth.whitening_state(0, 2048)
+    P, m = torch.from_numpy(lw["P"]), torch.from_numpy(lw["m"])
+    x = synth.synth_input(4, (2, 3, 128, 160))
+    for scales in (O.SCALE_PRESETS[True], O.SCALE_PRESETS["sms"]):
+        ref = torch.stack([O.embed_ms_whiten(x[i:i + 1], sd, "resnet101", scales, P, m) for i in range(2)])
+        net = engine.build_embedder(sd, cuda_device)
+        xd = x.to(cuda_device)
+        per_scale = torch.stack([net.forward(xd, scale=s)[net.out_slot] for s in scales])     # S x N x D
+        v = engine.ms_aggregate(per_scale, 3.0)
+        got = engine.whiten(v, P.to(cuda_device), m.to(cuda_device)).cpu()
+        assert float((got - ref).abs().max()) < 1e-3
+        for i in range(2):
+            assert _cos(got[i], ref[i]) > 0.9999
+
+
+def test_ms_aggregate_and_whiten_ops(cuda_device):
+    from gandtr_amd import engine
+    S, N, D = 3, 4, 512
+    v = synth._uniform(5, "v", (S, N, D), 0.0, 1.0)
+    v = v / v.norm(dim=2, keepdim=True)
+    lw = synth.whitening_state(1, D)
+    P, m = torch.from_numpy(lw["P"]), torch.from_numpy(lw["m"])
+    for msp in (1.0, 3.0, 2.37):
+        ref = torch.stack([O.ms_aggregate([v[s, n][:, None] for s in range(S)], msp) for n in range(N)])
+        got = engine.ms_aggregate(v.to(cuda_device), msp)
+        assert float((got.cpu() - ref).abs().max()) < 1e-6
+        for dims in (None, 128):
+            refw = torch.stack([O.whiten(ref[n], P, m, dims) for n in range(N)])
+            gotw = engine.whiten(got, P.to(cuda_device), m.to(cuda_device), dims).cpu()
+            assert float((gotw - refw).abs().max()) < 1e-5
+
+
+def test_hed_on_generator_output(cuda_device):
+    from gandtr_amd.engine import build_hed
+    sd = synth.hed_state(0)
+    y = synth.synth_input(6, (2, 3, 64, 96), 1.0)
+    ref = O.hed_on_generator_output(y, sd)
+    scale = [O.HED_MEANSTD_IN[1][c] / O.HED_MEANSTD_OUT[1][c] for c in range(3)]
+    shift = [(O.HED_MEANSTD_IN[0][c] - O.HED_MEANSTD_OUT[0][c]) / O.HED_MEANSTD_OUT[1][c] for c in range(3)]
+    net = build_hed(sd, cuda_device, perm=[2, 1, 0], in_affine=(scale, shift))
+    got = net.forward(y.to(cuda_device))[net.out_slot].cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 1e-3
