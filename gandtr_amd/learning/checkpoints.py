@@ -1,0 +1,16 @@
+"""Checkpoint reading for the hub path -- mirror of Checkpoints.load_network, mdir/learning/checkpoints.py:209-220.
+File format: {"type","frozen","network_params":{"model","runtime"},"model_state"} (mdir/learning/network.py:212-220)."""
+import torch
+
+from ..tools.utils import fs_open
+
+
+class Checkpoints:
+    @classmethod
+    def load_network(cls, directory):
+        if directory is None:
+            return None
+        with fs_open(str(directory)) as handle:
+            checkpoint = torch.load(handle, map_location="cpu", weights_only=False)
+        assert "net" not in checkpoint.get("_networks_included", {})
+        return {"net": checkpoint, **checkpoint.pop("_networks_included", {})}
