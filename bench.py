@@ -1,0 +1,188 @@
+"""bench.py -- headline benchmark of the gandtr hot path on MI355X (contract: see the task's bench section).
+
+metric (BASELINE.json): images/sec generator@256^2 + descriptors/sec GeM-R101@1024^2.
+  primary   `value`      : CycleGAN ResnetGenerator (InstanceNorm, 9 blocks) forward, batch 64x3x256x256 per GPU
+  secondary `secondary`  : GeM-ResNet-101 single-scale descriptors on 3x1024x1024, batch 16 per GPU, + all-gather for N>1
+A "step" is one pass of the hot path over one batch already resident in HBM.  One process per GPU; N>1 is launched by
+torch.distributed.run (RCCL); every rank processes its own batch (weak scaling), the only collective is the descriptor
+all-gather of the secondary workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gandtr_amd import engine, sharding          # noqa: E402
+from gandtr_amd.tools import synth               # noqa: E402
+
+PEAK_F16_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+GEN_GFLOP_PER_IMAGE = 99.10     # SURVEY.md section 8d (conv MACs x 2, hooks on the reference modules)
+R101_GFLOP_PER_IMAGE = 326.0
+
+
+def timed(fn, steps, warmup, dev, distributed):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def conv_roofline(net, x, steps=3):
+    """Live per-kernel timing (HIP events on the launch stream, recorded inside the library around every op): algorithmic
+    conv FLOPs / duration for the dominant kernel template conv_igemm_kernel<128,128,...>."""
+    net.set_profiling(True)
+    tot_ms, tot_fl, launches, all_ms = 0.0, 0.0, 0, 0.0
+    for _ in range(steps):
+        net.forward(x)
+        torch.cuda.synchronize()
+        for kind, tile, ms, fl in net.profile():
+            all_ms += ms
+            if kind == 1 and tile == 128:
+                tot_ms += ms
+                tot_fl += fl
+                launches += 1
+    net.set_profiling(False)
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel<128,128,2,2>", "launches_per_step": launches // steps,
+            "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3)}
+
+
+def cpu_baseline_generator(seconds=12.0):
+    """CPU oracle (the reference's torch ops restated, oracle/) on a bounded sample of the same workload."""
+    from oracle import gandtr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.generator_state(0, "instance", gain=0.02)
+    x = synth.synth_input(100, (4, 3, 256, 256), 1.0)
+    with torch.no_grad():
+        O.resnet_generator(x, sd, "instance", 9)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            O.resnet_generator(x, sd, "instance", 9)
+            n += 4
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images (4x3x256x256 batches) in %.1f s, torch CPU fp32 oracle, %d threads" % (n, dt, cores)}
+
+
+def cpu_baseline_r101(seconds=10.0):
+    from oracle import gandtr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.resnet101_state(0)
+    x = synth.synth_input(101, (1, 3, 1024, 1024))
+    with torch.no_grad():
+        O.image_retrieval_forward(x, sd, "resnet101")
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            O.image_retrieval_forward(x, sd, "resnet101")
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "descriptors/s", "cores": cores, "kind": "port",
+            "sample": "%d images (1x3x1024x1024) in %.1f s, torch CPU fp32 oracle, %d threads" % (n, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gen-batch", type=int, default=64)
+    ap.add_argument("--r101-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---------------------------------------------------------------- primary: generator images/s
+    gsd = synth.generator_state(0, "instance", gain=0.02)
+    gen = engine.build_generator(gsd, dev)
+    xg = synth.synth_input(1000 + rank, (a.gen_batch, 3, 256, 256), 1.0).to(dev)
+    dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
+    gen_ips = a.gen_batch * world * a.steps / dt
+    gen_ms = dt / a.steps * 1e3
+    roof = conv_roofline(gen, xg) if rank == 0 else None
+    gen_tflops = gen_ips * GEN_GFLOP_PER_IMAGE / 1e3 / world
+    del gen
+    torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- secondary: GeM-R101 descriptors/s @1024^2
+    secondary = None
+    if not a.no_secondary:
+        rsd = synth.resnet101_state(0)
+        emb = engine.build_embedder(rsd, dev)
+        xe = synth.synth_input(2000 + rank, (a.r101_batch, 3, 1024, 1024)).to(dev)
+        n_total = a.r101_batch * world
+
+        def step():
+            d = emb.forward(xe)[emb.out_slot]                       # n_local x D
+            if distributed:
+                d = sharding.all_gather_descriptors(d, n_total)     # D x N on every rank (RCCL all-gather)
+            return d
+        dt2 = timed(step, a.steps, a.warmup, dev, distributed)
+        r_dps = n_total * a.steps / dt2
+        roof2 = conv_roofline(emb, xe) if rank == 0 else None
+        secondary = {"metric": "descriptors/sec GeM-ResNet101 single-scale @1024x1024", "value": round(r_dps, 2),
+                     "unit": "descriptors/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+                     "config": {"workload": "gem_resnet101 forward + GeM + L2N (+ RCCL all-gather when N>1), synthetic 3x1024x1024",
+                                "batch_per_gpu": a.r101_batch, "parallelism": "dp%d" % world},
+                     "whole_net_tflops_per_gpu": round(r_dps * R101_GFLOP_PER_IMAGE / 1e3 / world, 1),
+                     "roofline": roof2}
+        del emb
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        line = {"metric": "images/sec generator@256^2 + descriptors/sec GeM-R101@1024^2, 1/2/4/8 MI355X",
+                "value": round(gen_ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(gen_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f16", "data": "synthetic",
+                "config": {"workload": "cyclegan ResnetGenerator 9-block (InstanceNorm) forward, synthetic 3x256x256, random-init weights",
+                           "batch_per_gpu": a.gen_batch, "global_batch": a.gen_batch * world, "parallelism": "dp%d" % world,
+                           "precision": "fp16 MFMA inputs, fp32 accumulate, fp16 NHWC activations"},
+                "whole_net_tflops_per_gpu": round(gen_tflops, 1),
+                "roofline": roof, "secondary": secondary}
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline_generator()
+            if secondary is not None:
+                secondary["cpu_baseline"] = cpu_baseline_r101()
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,10 @@ struct gdt_net {
     size_t zeros_off = 0;
     bool finalized = false;
     int input_op = -1;
+    // optional per-op timing (bench.py roofline): HIP events recorded on the caller's stream around every op
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<double> last_flops;
 
     size_t blob_append(const void* data, size_t bytes) {
         const size_t off = align_up(host_blob.size());
@@ -242,6 +246,7 @@ int gdt_net_create(gdt_net** net) {
 void gdt_net_destroy(gdt_net* net) {
     if (!net) return;
     if (net->dev_blob) (void)hipFree(net->dev_blob);
+    for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     delete net;
 }
 
@@ -447,26 +452,58 @@ int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes) 
     return GDT_OK;
 }
 
+static double op_flops(const gdt_net* net, const Op& o, int n, int rh, int rw) {
+    if (o.kind == OP_CONV) {
+        const Tensor& ti = net->tensors[o.in];
+        if (o.cd.transposed)   // every input pixel meets every kernel tap once
+            return 2.0 * n * ti.H * ti.W * (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw;
+        return 2.0 * n * (double)conv_out_dim(o.cd, ti.H, o.cd.kh) * conv_out_dim(o.cd, ti.W, o.cd.kw) * o.cd.cin * o.cd.cout *
+               o.cd.kh * o.cd.kw;
+    }
+    if (o.kind == OP_HED) {
+        double f = 2.0 * n * rh * rw * 5;
+        for (int k = 0; k < 5; ++k) { const Tensor& tf = net->tensors[o.feats[k]]; f += 2.0 * n * tf.H * tf.W * tf.C; }
+        return f;
+    }
+    return 0.0;
+}
+
 int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops) {
     GDT_REQUIRE(net && flops, "net");
     Plan plan;
     int rc = make_plan(net, n, rh, rw, plan);
     if (rc != GDT_OK) return rc;
     double f = 0.0;
-    for (const Op& o : net->ops) {
-        if (o.kind == OP_CONV) {
-            const Tensor& ti = net->tensors[o.in];
-            if (o.cd.transposed)   // every input pixel meets every kernel tap once
-                f += 2.0 * n * ti.H * ti.W * (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw;
-            else
-                f += 2.0 * n * (double)conv_out_dim(o.cd, ti.H, o.cd.kh) * conv_out_dim(o.cd, ti.W, o.cd.kw) * o.cd.cin * o.cd.cout *
-                     o.cd.kh * o.cd.kw;
-        } else if (o.kind == OP_HED) {
-            for (int k = 0; k < 5; ++k) { const Tensor& tf = net->tensors[o.feats[k]]; f += 2.0 * n * tf.H * tf.W * tf.C; }
-            f += 2.0 * n * rh * rw * 5;
-        }
-    }
+    for (const Op& o : net->ops) f += op_flops(net, o, n, rh, rw);
     *flops = f;
+    return GDT_OK;
+}
+
+int gdt_net_set_profiling(gdt_net* net, int enable) {
+    GDT_REQUIRE(net && net->finalized, "net must be finalized");
+    if (enable && net->events.empty()) {
+        net->events.resize(net->ops.size() * 2);
+        for (auto& e : net->events) GDT_CHECK_HIP(hipEventCreate(&e));
+    }
+    net->profiling = enable != 0;
+    return GDT_OK;
+}
+
+int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int* tile_n, double* ms, double* flops) {
+    GDT_REQUIRE(net && n_ops && kinds && tile_n && ms && flops, "profile buffers");
+    GDT_REQUIRE(!net->events.empty() && net->last_flops.size() == net->ops.size(), "no profiled forward has run");
+    const int n = (int)net->ops.size();
+    GDT_REQUIRE(max_ops >= n, "profile buffers too small");
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        GDT_CHECK_HIP(hipEventSynchronize(net->events[2 * i + 1]));
+        GDT_CHECK_HIP(hipEventElapsedTime(&t, net->events[2 * i], net->events[2 * i + 1]));
+        kinds[i] = (int)net->ops[i].kind;
+        tile_n[i] = net->ops[i].kind == OP_CONV ? gdt_conv_bn(net->ops[i].cd.cout) : 0;
+        ms[i] = t;
+        flops[i] = net->last_flops[i];
+    }
+    *n_ops = n;
     return GDT_OK;
 }
 
@@ -490,8 +527,13 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };
     const f16* zeros = (const f16*)(net->dev_blob + net->zeros_off);
 
+    if (net->profiling) {
+        net->last_flops.resize(net->ops.size());
+        for (size_t i = 0; i < net->ops.size(); ++i) net->last_flops[i] = op_flops(net, net->ops[i], n, rh, rw);
+    }
     for (const Step& stp : plan.steps) {
         const Op& o = net->ops[stp.op];
+        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * stp.op], st));
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
@@ -564,6 +606,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
             }
         }
         if (rc != GDT_OK) return rc;
+        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * stp.op + 1], st));
     }
     return GDT_OK;
 }

@@ -137,6 +137,18 @@ class HipNet:
         _hip.check(self.lib.gdt_net_flops(self.handle, n, rh, rw, ctypes.byref(f)))
         return f.value
 
+    def set_profiling(self, enable):
+        _hip.check(self.lib.gdt_net_set_profiling(self.handle, int(enable)))
+
+    def profile(self):
+        """per-op (kind, conv N-tile, ms, algorithmic flops) of the last profiled forward"""
+        cap = 1024
+        n = ctypes.c_int()
+        kinds, tiles = (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+        ms, fl = (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+        _hip.check(self.lib.gdt_net_profile_read(self.handle, cap, ctypes.byref(n), kinds, tiles, ms, fl))
+        return [(kinds[i], tiles[i], ms[i], fl[i]) for i in range(n.value)]
+
     def workspace_bytes(self, n, rh, rw):
         b = ctypes.c_size_t()
         _hip.check(self.lib.gdt_net_workspace_bytes(self.handle, n, rh, rw, ctypes.byref(b)))

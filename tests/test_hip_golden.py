@@ -1,0 +1,132 @@
+"""GPU path against the committed golden vectors (outputs of the imported reference, tests/golden/make_golden.py) and the
+hub / wrapper plumbing on a cuda device.  Generator tolerances: see DESIGN.md "Precision" -- single-pass fp16 MFMA."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import hubconf
+from gandtr_amd.learning import network as N
+from gandtr_amd.tools import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+load = lambda name: np.load(os.path.join(G, name + ".npz"))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(np.asarray(a)).float(), torch.as_tensor(np.asarray(b)).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_tiny_taps_vs_reference(cuda_device, norm):
+    g = load("gen_tiny_" + norm)
+    from gandtr_amd.components.model import network as M
+    gen = M.initialize_model({"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "ngf": 8,
+                              "n_blocks": 2, "norm_layer": norm}).eval()
+    gen.load_state_dict(synth.generator_state(0, norm, ngf=8, n_blocks=2))
+    gen.to(cuda_device)
+    taps = [1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 14, 15, 17, 19, 20]
+    with torch.no_grad():
+        out, feats = gen(synth.synth_input(1, (2, 3, 32, 32), 1.0).to(cuda_device), layers=list(taps))
+    assert rel(out.cpu(), g["out"]) < 5e-3
+    for t, f in zip(taps, feats):
+        assert rel(f.cpu(), g["tap%d" % t]) < 5e-3, t
+
+
+@pytest.mark.parametrize("name", ["cyclegan", "hedngan"])
+def test_hub_generator_on_gpu(cuda_device, name):
+    """hub entrypoint on the GPU: same seeded weights as the reference, output vs the reference's CPU output"""
+    g = load("hub_" + name)
+    net = getattr(hubconf, name)(pretrained=False, device=cuda_device)
+    x = synth.synth_input(3, (4, 3, 256, 256), 1.0)
+    with torch.no_grad():
+        y = net(x)
+    assert y.is_cuda and y.shape == (4, 3, 256, 256)
+    y = y.cpu()
+    # gain-0.2 init saturates tanh: compare the statistics and the sub-sampled image loosely; the tight
+    # pre-tanh comparison lives in test_hip_models.py
+    assert float((y[:, :, ::8, ::8] - torch.from_numpy(g["out_sub"])).abs().mean()) < 5e-3
+
+
+@pytest.mark.parametrize("arch,p", [("vgg16", 3.0), ("resnet101", 2.37)])
+def test_embedder_hub_paths_on_gpu(cuda_device, arch, p, tmp_path):
+    g = load("embed_" + arch)
+    state = synth.vgg16_state(0, p=p) if arch == "vgg16" else synth.resnet101_state(0, p=p)
+    params = {"type": "SingleNetwork",
+              "model": {"architecture": "cirnet", "cir_architecture": arch, "local_whitening": False, "pooling": "gem",
+                        "pretrained": False, "regional": False, "whitening": False},
+              "initialize": False,
+              "runtime": {"data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]},
+                          "wrappers": "cirfaketuplebatch"}}
+    net = N.initialize_network(params, cuda_device).eval()
+    net.model.load_state_dict(state)
+    x = synth.synth_input(7, (2, 3, 96, 128))
+    with torch.no_grad():
+        d = net(x)
+    assert d.is_cuda and d.shape == g["ss"].shape                     # D x N
+    ref = torch.from_numpy(g["ss"])
+    assert float((d.cpu() - ref).abs().max()) < 1e-3
+    assert float(torch.nn.functional.cosine_similarity(d.cpu().t(), ref.t(), dim=1).min()) > 0.9999
+    # pretrained-style path: whiten + multiscale wrappers, pyramid fused into the HIP pack kernel
+    ck = tmp_path / "net.pth"
+    cpu_sd = {"type": "SingleNetwork", "frozen": False, "network_params": net.network_params._asdict(),
+              "model_state": {k: v.cpu() for k, v in net.model.state_dict().items()}}
+    torch.save(cpu_sd, ck)
+    lwp = tmp_path / "lw.pkl"
+    with open(lwp, "wb") as f:
+        pickle.dump(synth.whitening_state(3, g["ss"].shape[0]), f)
+    from gandtr_amd.learning.checkpoints import Checkpoints
+    for tag, scales in (("ms", True), ("sms", "sms")):
+        runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": str(lwp), "dimensions": None},
+                                                        "1_cirmultiscale": {"scales": scales}}}}
+        hub = N.initialize_network(None, cuda_device, Checkpoints.load_network(str(ck)), runtime).eval()
+        refh = torch.from_numpy(g["hub_" + tag])                      # 2 x D
+        with torch.no_grad():
+            one = hub(x[0:1].clone())
+            both = hub(x.clone())
+        assert one.shape == (refh.shape[1],) and both.shape == (refh.shape[1], 2)
+        assert float((one.cpu() - refh[0]).abs().max()) < 1e-3
+        assert float((both.cpu().t() - refh).abs().max()) < 1e-3
+        assert float(torch.nn.functional.cosine_similarity(both.cpu().t(), refh, dim=1).min()) > 0.9999
+
+
+def test_hed_with_wrappers_on_gpu(cuda_device):
+    g = load("hed")
+    params = {"type": "SingleNetwork", "model": {"architecture": "hed_interpolation"}, "initialize": False,
+              "runtime": {"wrappers": "rgb2bgr_pre, meanstd_pre:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.40787054,0.45752458,0.48109378],[1,1,1]]"}}
+    net = N.initialize_network(params, cuda_device).eval()
+    net.model.load_state_dict(synth.hed_state(0))
+    with torch.no_grad():
+        out = net(synth.synth_input(8, (2, 3, 64, 96), 1.0))
+    assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
+
+
+def test_chain_config5_on_gpu(cuda_device):
+    g = load("chain_c5")
+    gen = {"type": "SingleNetwork",
+           "model": {"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "n_blocks": 9,
+                     "norm_layer": "instance", "no_antialias": True, "no_antialias_up": True},
+           "initialize": False,
+           "runtime": {"wrappers": "meanstd_post:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.485,0.456,0.406],[0.229,0.224,0.225]]",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "resnet101", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False,
+           "runtime": {"wrappers": "cirfaketuplebatch",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen, "embed": emb},
+                                 cuda_device).eval()
+    chain.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance", gain=0.02))
+    chain.networks["embed"].model.load_state_dict(synth.resnet101_state(0, p=3.0))
+    with torch.no_grad():
+        d = chain(synth.synth_input(9, (2, 3, 128, 128), 1.0))
+    ref = torch.from_numpy(g["out"])
+    assert d.shape == ref.shape
+    assert float(torch.nn.functional.cosine_similarity(d.cpu().t(), ref.t(), dim=1).min()) > 0.9999
+    assert float((d.cpu() - ref).abs().max()) < 1e-3

@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference interface on CPU: hub entrypoints (reference test: test/integration/hub/
+test_hub_init.py:17-20), registries, wrappers, containers -- checked against golden vectors from the imported reference."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import hubconf
+from gandtr_amd.components.data import wrapper as W
+from gandtr_amd.components.model import network as M
+from gandtr_amd.learning import network as N
+from gandtr_amd.tools import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+load = lambda name: np.load(os.path.join(G, name + ".npz"))
+
+ENTRYPOINTS = ["gem_vgg16_cyclegan", "gem_resnet101_cyclegan", "gem_vgg16_hedngan", "gem_resnet101_hedngan", "cyclegan",
+               "hedngan"]
+
+
+def close(a, b, tol=2e-6):
+    a, b = torch.as_tensor(np.asarray(a)), torch.as_tensor(np.asarray(b))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_can_initialize_base_models():
+    """== reference test_can_initialize_base_models; plus the attribute surface listed in SURVEY.md section 8b"""
+    for name in ENTRYPOINTS:
+        net = getattr(hubconf, name)(pretrained=False, device="cpu")
+        assert net is not None and net.stage == "eval" and not net.model.training
+        for attr in ("model", "wrappers", "network_params", "meta", "stage", "device", "frozen", "transform", "forward",
+                     "forward_batch", "eval", "train", "freeze", "parameters", "state_dict", "overlay_params", "overlay_model"):
+            assert hasattr(net, attr), (name, attr)
+        assert set(net.wrappers) == {"train", "eval"}
+        assert set(net.state_dict()["net"]) == {"type", "frozen", "network_params", "model_state"}
+    assert hubconf.dependencies
+
+
+def test_pretrained_needs_network():
+    """pretrained=True downloads from ptak.felk.cvut.cz (mdir/hub/model.py:5); offline it must raise, not fall back"""
+    with pytest.raises(Exception):
+        hubconf.cyclegan(pretrained=True, device="cpu")
+
+
+@pytest.mark.parametrize("name", ["cyclegan", "hedngan"])
+def test_hub_generator_reproduces_reference_init_and_output(name):
+    """seed-0 normal_p2p / kaiming_p2p initialisation (network.py:159-162) gives the reference's weights bit for bit, and
+    the CPU forward (BASELINE config 0: 4x3x256x256) gives the reference's output"""
+    g = load("hub_" + name)
+    net = getattr(hubconf, name)(pretrained=False, device="cpu")
+    sd = net.model.state_dict()
+    assert sorted(sd.keys()) == list(g["keys"])
+    for k, s, a in zip(g["keys"], g["wsum"], g["wabs"]):
+        assert float(sd[k].double().sum()) == pytest.approx(s, rel=1e-12, abs=1e-12), k
+        assert float(sd[k].double().abs().sum()) == pytest.approx(a, rel=1e-12, abs=1e-12), k
+    x = synth.synth_input(3, (4, 3, 256, 256), 1.0)
+    with torch.no_grad():
+        y = net(x)
+    close(y[:, :, ::8, ::8], g["out_sub"], 1e-5)
+    close(y.mean(dim=(2, 3)), g["out_mean"], 1e-5)
+
+
+def test_transform_repr_matches_readme():
+    """README.md:132-138"""
+    net = hubconf.gem_vgg16_hedngan(pretrained=False, device="cpu")
+    assert repr(net.transform) == ("Compose(\n    Pil2Numpy()\n    ApplyClahe(clip_limit=1.0, grid_size=8, colorspace=lab)\n"
+                                   "    ToTensor()\n    Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], "
+                                   "strict_shape=True)\n)")
+    gen = hubconf.cyclegan(pretrained=False, device="cpu")
+    img = (np.random.RandomState(0).rand(8, 9, 3) * 255).astype(np.uint8)
+    t = gen.transform(img)
+    assert t.shape == (3, 8, 9) and float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+
+
+def test_registries_and_errors():
+    assert {"official_resnet_generator", "cirnet", "hed_interpolation"} <= set(M.MODEL_LABELS)
+    assert {"cirmultiscale", "cirwhiten", "cirfaketuplebatch", "fakebatch", "meanstd_post", "meanstd_pre", "rgb2bgr_pre",
+            "clahepost"} <= set(W.WRAPPERS_LABELS)
+    assert {"SingleNetwork", "CirSequentialNetwork"} <= set(N.NETWORKS)
+    with pytest.raises(KeyError):
+        M.initialize_model({"architecture": "no_such_model"})
+    with pytest.raises(KeyError):
+        W.initialize_wrappers("no_such_wrapper", "cpu")
+    with pytest.raises(ValueError):
+        M.initialize_model({"architecture": "cirnet", "cir_architecture": "vgg16"})          # missing keys (cirnet.py:49-51)
+    with pytest.raises(ValueError):
+        M.initialize_model({"architecture": "cirnet", "cir_architecture": "alexnet9", "local_whitening": False,
+                            "pooling": "gem", "regional": False, "whitening": False, "pretrained": False})
+    with pytest.raises(NotImplementedError):
+        M.initialize_model({"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "norm_layer": "group"})
+    with pytest.raises(AssertionError):      # unknown runtime key (network.py:128-131)
+        N.initialize_network({"type": "SingleNetwork", "model": {"architecture": "identity"}, "initialize": False,
+                              "runtime": {"wrappers": "", "bogus": 1}}, "cpu")
+
+
+def test_wrapper_order_and_dsl():
+    w = W.initialize_wrappers({"1_cirmultiscale": {"scales": True}, "0_cirwhiten":
+                               {"whitening": synth.whitening_state(0, 8), "dimensions": None}}, "cpu")
+    assert [type(x).__name__ for x in w.wrappers] == ["CirtorchWhiten", "CirMultiscaleAggregation"]
+    w = W.initialize_wrappers("rgb2bgr_pre, meanstd_pre:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.4,0.45,0.48],[1,1,1]]", "cpu")
+    assert [type(x).__name__ for x in w.wrappers] == ["RgbToBgrPre", "MeanStdPre"]
+    assert W.CirMultiscaleAggregation("sms", "cpu").scales == [1, 1. / np.sqrt(2), np.sqrt(2)]
+    assert W.CirMultiscaleAggregation(True, "cpu").scales == [1, 1. / np.sqrt(2), 1. / 2]
+
+
+def test_wrappers_against_reference_vectors():
+    g = load("wrappers")
+    img = synth.synth_input(5, (1, 3, 40, 56))
+    for tag, sc in (("ms", "True"), ("sms", "sms")):
+        levels, waslist = W.CirMultiscaleAggregation(sc, "cpu").preprocess(img, None)
+        assert not waslist
+        for i, lvl in enumerate(levels):
+            close(lvl, g["pyr_%s_%d" % (tag, i)])
+    vecs = torch.from_numpy(g["vecs"])
+    lw = synth.whitening_state(2, 64)
+    for msp in (1.0, 3.0, 2.37):
+        agg = W.CirMultiscaleAggregation.aggregate_tensor([v.clone() for v in vecs], 3, 64, msp)
+        close(agg, g["agg_msp%s" % msp])
+        for dims in (None, 16):
+            close(W.CirtorchWhiten(lw, dims, "cpu").postprocess(agg.clone(), None, None), g["whiten_msp%s_d%s" % (msp, dims)])
+    ms = W.MeanStdPost("[[0.5,0.5,0.5],[0.5,0.5,0.5]]", "[[0.485,0.456,0.406],[0.229,0.224,0.225]]", device="cpu")
+    close(ms.postprocess(img.clone(), None, None), g["meanstd_post"])
+    sc, sh = ms.affine()
+    close(img * torch.tensor(sc)[None, :, None, None] + torch.tensor(sh)[None, :, None, None], g["meanstd_post"], 1e-5)
+
+
+def _embedder(arch, state, wrappers):
+    params = {"type": "SingleNetwork",
+              "model": {"architecture": "cirnet", "cir_architecture": arch, "local_whitening": False, "pooling": "gem",
+                        "pretrained": False, "regional": False, "whitening": False},
+              "initialize": False,
+              "runtime": {"data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]},
+                          "wrappers": wrappers}}
+    net = N.initialize_network(params, "cpu").eval()
+    net.model.load_state_dict(state)
+    return net
+
+
+@pytest.mark.parametrize("arch,p", [("vgg16", 3.0), ("resnet101", 2.37)])
+def test_embedder_paths(arch, p, tmp_path):
+    g = load("embed_" + arch)
+    state = synth.vgg16_state(0, p=p) if arch == "vgg16" else synth.resnet101_state(0, p=p)
+    x = synth.synth_input(7, (2, 3, 96, 128))
+    net = _embedder(arch, state, "cirfaketuplebatch")
+    with torch.no_grad():
+        close(net(x), g["ss"])                                              # D x N
+    # pretrained-style path: checkpoint file + lw.pkl -> whiten + multiscale wrappers (hub/model.py:30-34)
+    ck = tmp_path / "net.pth"
+    torch.save(net.state_dict()["net"], ck)
+    lwp = tmp_path / "lw.pkl"
+    with open(lwp, "wb") as f:
+        pickle.dump(synth.whitening_state(3, g["ss"].shape[0]), f)
+    from gandtr_amd.learning.checkpoints import Checkpoints
+    for tag, scales in (("ms", True), ("sms", "sms")):
+        runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": str(lwp), "dimensions": None},
+                                                        "1_cirmultiscale": {"scales": scales}}}}
+        hub = N.initialize_network(None, "cpu", Checkpoints.load_network(str(ck)), runtime).eval()
+        with torch.no_grad():
+            single = torch.stack([hub(x[i:i + 1].clone()) for i in range(2)])
+            batched = hub(x.clone())                                        # extension: batch > 1 == stack of singles (D4)
+        close(single, g["hub_" + tag], 5e-6)
+        assert single[0].shape == (g["ss"].shape[0],)
+        close(batched.t(), g["hub_" + tag], 5e-6)
+
+
+def test_hed_with_wrappers():
+    g = load("hed")
+    params = {"type": "SingleNetwork", "model": {"architecture": "hed_interpolation"}, "initialize": False,
+              "runtime": {"wrappers": "rgb2bgr_pre, meanstd_pre:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.40787054,0.45752458,0.48109378],[1,1,1]]"}}
+    net = N.initialize_network(params, "cpu").eval()
+    net.model.load_state_dict(synth.hed_state(0))
+    with torch.no_grad():
+        close(net(synth.synth_input(8, (2, 3, 64, 96), 1.0)), g["out"])
+
+
+def test_cir_sequential_chain_config5():
+    g = load("chain_c5")
+    gen = {"type": "SingleNetwork",
+           "model": {"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "n_blocks": 9,
+                     "norm_layer": "instance", "no_antialias": True, "no_antialias_up": True},
+           "initialize": False,
+           "runtime": {"wrappers": "meanstd_post:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.485,0.456,0.406],[0.229,0.224,0.225]]",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "resnet101", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False,
+           "runtime": {"wrappers": "cirfaketuplebatch",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen, "embed": emb},
+                                 "cpu").eval()
+    chain.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance", gain=0.02))
+    chain.networks["embed"].model.load_state_dict(synth.resnet101_state(0, p=3.0))
+    with torch.no_grad():
+        close(chain(synth.synth_input(9, (2, 3, 128, 128), 1.0)), g["out"], 5e-6)
+
+
+def test_generator_taps_cpu():
+    """feature taps (p2p_networks.py:316-334) incl. the in-place ReLU aliasing, against the reference vectors"""
+    g = load("gen_tiny_instance")
+    gen = M.initialize_model({"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "ngf": 8,
+                              "n_blocks": 2, "norm_layer": "instance"}).eval()
+    gen.load_state_dict(synth.generator_state(0, "instance", ngf=8, n_blocks=2))
+    with torch.no_grad():
+        out, feats = gen(synth.synth_input(1, (2, 3, 32, 32), 1.0), layers=[1, 2, 3, 10, 19])
+    close(out, g["out"])
+    for f, i in zip(feats, [1, 2, 3, 10, 19]):
+        close(f, g["tap%d" % i])
