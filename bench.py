@@ -71,10 +71,19 @@ def conv_roofline(net, x, steps=3):
             "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3)}
 
 
+def host_cores():
+    """threads for the CPU baseline: the cores this process may run on, capped at the GPU box's per-GPU CPU share (16)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline_generator(seconds=12.0):
     """CPU oracle (the reference's torch ops restated, oracle/) on a bounded sample of the same workload."""
     from oracle import gandtr_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth.generator_state(0, "instance", gain=0.02)
     x = synth.synth_input(100, (4, 3, 256, 256), 1.0)
@@ -91,7 +100,7 @@ def cpu_baseline_generator(seconds=12.0):
 
 def cpu_baseline_r101(seconds=10.0):
     from oracle import gandtr_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth.resnet101_state(0)
     x = synth.synth_input(101, (1, 3, 1024, 1024))

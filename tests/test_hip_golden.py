@@ -102,7 +102,7 @@ def test_hed_with_wrappers_on_gpu(cuda_device):
     net = N.initialize_network(params, cuda_device).eval()
     net.model.load_state_dict(synth.hed_state(0))
     with torch.no_grad():
-        out = net(synth.synth_input(8, (2, 3, 64, 96), 1.0))
+        out = net(synth.synth_input(8, (2, 3, 64, 96), 1.0).to(cuda_device))   # the generator output lives on the device
     assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
 
 
