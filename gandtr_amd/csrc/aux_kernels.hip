@@ -118,6 +118,27 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     mean_rstd[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// stage 2 (fused-statistics variant): the partials were written by the conv epilogue, one [2][C] record per 128-row tile;
+// tile index = phase * (N * tpi) + n * tpi + t   (phases: 1 for Conv2d, 4 for the ConvTranspose2d sub-pixel launches)
+__global__ __launch_bounds__(256) void in_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
+                                                                int tpi, int nphase, int N, int C, int HW, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    double s = 0.0, q = 0.0;
+    for (int ph = 0; ph < nphase; ++ph)
+        for (int t = 0; t < tpi; ++t) {
+            const long tile = (long)ph * N * tpi + (long)n * tpi + t;
+            s += (double)partial[(tile * 2 + 0) * C + c];
+            q += (double)partial[(tile * 2 + 1) * C + c];
+        }
+    const double m = s / HW;
+    double var = q / HW - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    mean_rstd[(long)i * 2 + 0] = (float)m;
+    mean_rstd[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // stage 3: y = relu?((x - mean) * rstd) (+ residual)
 __global__ __launch_bounds__(256) void in_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean_rstd,
                                                        const f16* __restrict__ res, f16* __restrict__ y,
@@ -258,6 +279,36 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const f16* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ row-split conv head
+// Second half of a k x k conv with very few output channels (generator head 64 -> 3, k = 7, p2p_networks.py:309-311).  The
+// implicit GEMM computed P[n][y][x'][kx*cout + co] = sum_{ky,c} in[y+ky-pad][x'][c] * W[co][c][ky][kx] (a k x 1 conv with
+// k*cout output channels, so the MFMA N tile is 21/32 used instead of 3/32); this kernel adds the k horizontally shifted
+// partials, the bias and the activation and writes fp32 NCHW.
+__global__ __launch_bounds__(256) void rowsplit_combine_kernel(const f16* __restrict__ P, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int N, int H, int W, int cp, int cout,
+                                                               int kw, int pad, int reflect, int act) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const long row = i / W;                       // n * H + y
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kx = 0; kx < kw; ++kx) {
+            int xs = x + kx - pad;
+            if (reflect) xs = xs < 0 ? -xs : (xs >= W ? 2 * W - 2 - xs : xs);
+            else if ((unsigned)xs >= (unsigned)W) continue;
+            const f16* p = P + (row * W + xs) * cp + kx * cout;
+            for (int co = 0; co < cout; ++co) acc[co] += (float)p[co];
+        }
+        const long n = row / H; const int y = (int)(row % H);
+        for (int co = 0; co < cout; ++co) {
+            float v = acc[co] + (bias ? bias[co] : 0.f);
+            if (act == 1) v = tanhf(v);
+            else if (act == 2) v = 1.f / (1.f + __expf(-v));
+            out[((n * cout + co) * H + y) * W + x] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ HED head
 // score[n][p] = b + sum_c x[n][p][c] * w[c]; one wavefront per pixel group of 8 (8 lanes per pixel)
 __global__ __launch_bounds__(256) void hed_score_kernel(const f16* __restrict__ x, const float* __restrict__ w, float bias,
@@ -351,6 +402,18 @@ int gdt_k_instance_norm(const f16* x, const f16* res, f16* y, float* partial, fl
     return GDT_OK;
 }
 
+int gdt_k_instance_norm_fused(const f16* x, const f16* res, f16* y, const float* tile_partials, int tiles_per_image, int nphase,
+                              float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st) {
+    hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, tile_partials, mean_rstd,
+                       tiles_per_image, nphase, N, C, HW, eps);
+    GDT_CHECK_HIP(hipGetLastError());
+    const long total8 = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, (const float*)mean_rstd, res, y, (long)HW, C,
+                       relu, total8);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
 int gdt_k_maxpool(const f16* x, f16* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
     GDT_REQUIRE(C % 8 == 0, "maxpool needs C % 8 == 0");
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long)N * OH * OW * (C / 8))), dim3(256), 0, st, x, y, N, H, W, C, OH,
@@ -393,6 +456,15 @@ int gdt_k_whiten(const float* P, const float* m, const float* v, float* tmp, flo
 
 int gdt_k_unpack_output(const f16* x, float* y, const float* bias, int N, int HW, int C, hipStream_t st) {
     hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, st, x, y, bias, N, HW, C);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_rowsplit_combine(const f16* P, const float* bias, float* out, int N, int H, int W, int cp, int cout, int kw, int pad,
+                           int reflect, int act, hipStream_t st) {
+    GDT_REQUIRE(cout >= 1 && cout <= 4, "row-split head supports up to 4 output channels");
+    hipLaunchKernelGGL(rowsplit_combine_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, st, P, bias, out, N, H, W, cp, cout,
+                       kw, pad, reflect, act);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

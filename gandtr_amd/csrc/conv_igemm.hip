@@ -178,21 +178,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
     __syncthreads();             // all MFMA reads of the staging buffers are done
     f16* Ct = (f16*)smem;
     const bool relu_now = d.relu && !d.res;
+    constexpr int STATS_OFF = (BM * CP * 2 + 255) / 256 * 256;     // [WGM][BN][2] floats behind the C tile
+    float* sl = (float*)(smem + STATS_OFF);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = wn * WTN + j * 32 + fr;
         const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                 float v = acc[i][j][e] + bv;
+                s1 += v; s2 += v * v;
                 if (relu_now) v = fmaxf(v, 0.f);
                 Ct[row * CP + col] = (f16)v;
             }
+        if (d.stats) {
+            // InstanceNorm partial statistics of this tile from the fp32 accumulators: per-lane column sums over the
+            // wave's rows, the two half-waves combined, then a fixed-order sum over the wave rows below (deterministic)
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (fh == 0) { sl[(wm * BN + col) * 2 + 0] = s1; sl[(wm * BN + col) * 2 + 1] = s2; }
+        }
     }
     __syncthreads();
+    if (d.stats && tid < BN) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) { s1 += sl[(w * BN + tid) * 2 + 0]; s2 += sl[(w * BN + tid) * 2 + 1]; }
+        const int gcol = tile_n * BN + tid;
+        if (gcol < d.Cout) {
+            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m) * 2) * d.Cout + gcol;
+            dst[0] = s1; dst[d.Cout] = s2;
+        }
+    }
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
     constexpr int NCH = BM * CPR / 256;         // chunks per thread
 #pragma unroll
@@ -224,7 +244,8 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     const int ntm = (d.M + BM - 1) / BM, ntn = d.CoutPad / BN;
     const int ntm8 = (ntm + 7) / 8 * 8;
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    static_assert((size_t)BM * (BN + 8) * 2 <= 2 * (size_t)(BM + BN) * ROWB, "epilogue tile must fit the staging LDS");
+    static_assert(((size_t)BM * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8 <= 2 * (size_t)(BM + BN) * ROWB,
+                  "epilogue tile + stats scratch must fit the staging LDS");
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(256), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
@@ -241,6 +262,8 @@ int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream) {
     GDT_REQUIRE(d.ntaps * d.Cin <= d.Kpad, "Kpad too small");
     GDT_REQUIRE(d.out_f32 || (d.Cout % 8 == 0), "fp16 NHWC output needs Cout % 8 == 0");
     GDT_REQUIRE(d.M > 0 && d.zeros != nullptr, "empty launch");
+    if (d.stats) GDT_REQUIRE(!d.out_f32 && !d.res && !d.relu && d.M % 128 == 0 && (d.OHg * d.OWg) % 128 == 0,
+                             "fused InstanceNorm statistics need whole 128-row tiles per image and a plain conv epilogue");
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
     if (d.pad_reflect) {

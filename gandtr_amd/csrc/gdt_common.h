@@ -49,7 +49,7 @@ struct ConvLaunch {
     const f16* res;       // residual, same layout as out, or nullptr
     f16* out;             // [N][OH][OW][Cout]  (nullptr when out_f32 is used)
     float* out_f32;       // [N][Cout][OH][OW] fp32 NCHW, or nullptr
-    float* stats;         // per-tile partial sums [M/BM tiles][2][Cout] for InstanceNorm, or nullptr
+    float* stats;         // per-tile partial sums [tiles][2][Cout] (sum, sum of squares) for InstanceNorm, or nullptr
     const f16* zeros;     // >= 16 B of zeros (source for padded / out-of-range chunks)
     int N, H, W, Cin, lc8;        // lc8 = log2(Cin / 8)
     int Cout, CoutPad, Kpad, nk;  // nk = Kpad / 64

@@ -44,6 +44,11 @@ struct Op {
     int in_c = 0; int perm[8]; float scale[8], shift[8];
     // inorm
     float eps = 1e-5f; int relu = 0;
+    int stats_from = -1;   // INORM: index of the conv op whose epilogue can deliver the statistics
+    int stats_for = -1;    // CONV: index of the INORM op consuming this conv's output
+    // CONV with few output channels written as fp32 NCHW (generator head): k x 1 implicit GEMM with kw*cout channels into a
+    // scratch tensor + horizontal combine (rowsplit_combine_kernel)
+    bool rowsplit = false; int rs_cout8 = 0; size_t rs_bias_off = 0;
     // maxpool
     int k = 0, s = 0, p = 0;
     // gem
@@ -122,7 +127,7 @@ struct gdt_net {
 
 namespace {
 
-struct Step { int op; size_t aux_off[8]; };
+struct Step { int op; size_t aux_off[8]; bool fused_stats; int tiles_per_image; };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
 
 int conv_out_dim(const gdt_conv_desc& c, int in, int k) {
@@ -143,6 +148,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     }
     Arena arena;
     plan.steps.clear();
+    std::vector<size_t> slab_off(net->ops.size(), 0), slab_bytes(net->ops.size(), 0);
     for (size_t i = 0; i < net->ops.size(); ++i) {
         const Op& o = net->ops[i];
         Step st{}; st.op = (int)i;
@@ -162,15 +168,38 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 if (o.cd.pad_reflect) GDT_REQUIRE(o.cd.pad < ti.H && o.cd.pad < ti.W, "reflection padding needs pad < input size");
                 if (o.out >= 0) rc = set_out(oh, ow);
                 if (o.res >= 0) GDT_REQUIRE(T[o.res].H == oh && T[o.res].W == ow, "residual shape mismatch");
+                if (o.rowsplit) {
+                    const size_t b = (size_t)N * oh * ti.W * o.rs_cout8 * sizeof(f16);
+                    st.aux_off[1] = arena.alloc(b);
+                    arena.release(st.aux_off[1], b);
+                }
+                if (o.stats_for >= 0 && rc == GDT_OK) {
+                    // fused InstanceNorm statistics: possible when every 128-row tile lies inside one image
+                    const int hwg = o.cd.transposed ? ti.H * ti.W : oh * ow;
+                    if (hwg % 128 == 0 && !o.cd.relu && o.res < 0) {
+                        const size_t tiles = (size_t)o.phases.size() * N * (hwg / 128);
+                        st.fused_stats = true; st.tiles_per_image = hwg / 128;
+                        slab_bytes[i] = tiles * 2 * o.cd.cout * sizeof(float);
+                        st.aux_off[0] = arena.alloc(slab_bytes[i]);
+                        slab_off[i] = st.aux_off[0];
+                    }
+                }
                 break;
             }
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
                 rc = set_out(ti.H, ti.W);
-                const int chunks = gdt_in_stats_chunks(ti.H * ti.W);
-                st.aux_off[0] = arena.alloc((size_t)N * chunks * 2 * ti.C * sizeof(float));
                 st.aux_off[1] = arena.alloc((size_t)N * ti.C * 2 * sizeof(float));
-                arena.release(st.aux_off[0], (size_t)N * chunks * 2 * ti.C * sizeof(float));
+                if (o.stats_from >= 0 && slab_bytes[o.stats_from]) {
+                    st.fused_stats = true;
+                    st.tiles_per_image = plan.steps[o.stats_from].tiles_per_image;
+                    st.aux_off[0] = slab_off[o.stats_from];
+                    arena.release(slab_off[o.stats_from], slab_bytes[o.stats_from]);
+                } else {
+                    const int chunks = gdt_in_stats_chunks(ti.H * ti.W);
+                    st.aux_off[0] = arena.alloc((size_t)N * chunks * 2 * ti.C * sizeof(float));
+                    arena.release(st.aux_off[0], (size_t)N * chunks * 2 * ti.C * sizeof(float));
+                }
                 arena.release(st.aux_off[1], (size_t)N * ti.C * 2 * sizeof(float));
                 break;
             }
@@ -286,12 +315,19 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
     if (residual_tensor >= 0) GDT_REQUIRE(net->tensors[residual_tensor].C == cd.cout && !cd.out_f32_nchw, "residual channels");
 
     Op o; o.kind = OP_CONV; o.in = in_tensor; o.res = residual_tensor; o.cd = cd; o.cin_pad = cin_pad;
-    const int bn_tile = gdt_conv_bn(cd.cout);
-    o.cout_pad = (cd.cout + bn_tile - 1) / bn_tile * bn_tile;
+    o.rowsplit = cd.out_f32_nchw && !cd.transposed && cd.stride == 1 && cd.kw >= 3 && cd.cout <= 4 && cd.cout * cd.kw <= 32 &&
+                 cd.kw == 2 * cd.pad + 1 && !cd.relu && !bn_gamma;
+    const int gemm_cout = o.rowsplit ? cd.cout * cd.kw : cd.cout;
+    if (o.rowsplit) o.rs_cout8 = (gemm_cout + 7) / 8 * 8;
+    const int bn_tile = gdt_conv_bn(gemm_cout);
+    o.cout_pad = (gemm_cout + bn_tile - 1) / bn_tile * bn_tile;
 
     std::vector<float> scale, shift; bool has_shift;
     fold_bn(cd, bias, bn_gamma, bn_beta, bn_mean, bn_var, scale, shift, has_shift);
-    if (has_shift) {
+    if (has_shift && o.rowsplit) {
+        o.rs_bias_off = net->blob_append(shift.data(), shift.size() * sizeof(float));
+        o.has_bias = true;     // applied by the combine kernel, not by the GEMM epilogue
+    } else if (has_shift) {
         std::vector<float> bp(o.cout_pad, 0.f);
         std::copy(shift.begin(), shift.end(), bp.begin());
         o.bias_off = net->blob_append(bp.data(), bp.size() * sizeof(float));
@@ -309,7 +345,21 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
     };
 
-    if (!cd.transposed) {
+    if (o.rowsplit) {
+        PackedPhase ph;
+        ph.ntaps = cd.kh; ph.TW = 1; ph.dy0 = -cd.pad; ph.dys = 1; ph.dx0 = 0; ph.dxs = 0;
+        const int K = ph.ntaps * cin_pad;
+        ph.Kpad = (K + 63) / 64 * 64;
+        std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f);
+        for (int kx = 0; kx < cd.kw; ++kx)
+            for (int co = 0; co < cd.cout; ++co)
+                for (int ky = 0; ky < cd.kh; ++ky)
+                    for (int c = 0; c < cd.cin; ++c)
+                        pk[(size_t)(kx * cd.cout + co) * ph.Kpad + (size_t)ky * cin_pad + c] =
+                            (f16)weight[(((size_t)co * cd.cin + c) * cd.kh + ky) * cd.kw + kx];
+        ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+        o.phases.push_back(ph);
+    } else if (!cd.transposed) {
         PackedPhase ph;
         ph.ntaps = cd.kh * cd.kw; ph.TW = cd.kw; ph.dy0 = -cd.pad; ph.dys = 1; ph.dx0 = -cd.pad; ph.dxs = 1;
         const int khw = cd.kh * cd.kw;
@@ -352,6 +402,11 @@ int gdt_net_instance_norm(gdt_net* net, int in_tensor, float eps, int relu, int 
     if (residual_tensor >= 0) GDT_REQUIRE(net->tensors[residual_tensor].C == C, "residual channels");
     Op o; o.kind = OP_INORM; o.in = in_tensor; o.res = residual_tensor; o.eps = eps; o.relu = relu;
     o.out = net->new_tensor(C);
+    for (size_t k = 0; k < net->ops.size(); ++k)
+        if (net->ops[k].kind == OP_CONV && net->ops[k].out == in_tensor && net->ops[k].stats_for < 0) {
+            net->ops[k].stats_for = (int)net->ops.size();
+            o.stats_from = (int)k;
+        }
     net->ops.push_back(o);
     *out_tensor = o.out;
     return GDT_OK;
@@ -550,9 +605,12 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 d.N = n; d.H = ti.H; d.W = ti.W; d.Cin = o.cin_pad; d.lc8 = ilog2(o.cin_pad / 8);
                 d.Cout = o.cd.cout; d.CoutPad = o.cout_pad;
                 d.OH = conv_out_dim(o.cd, ti.H, o.cd.kh); d.OW = conv_out_dim(o.cd, ti.W, o.cd.kw);
-                if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
+                if (o.rowsplit) { d.out = (f16*)(ws + stp.aux_off[1]); d.out_f32 = nullptr; d.Cout = o.rs_cout8; d.OW = ti.W; d.bias = nullptr; }
+                else if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
                 else { d.out = tptr(o.out); d.out_f32 = nullptr; }
                 d.pad_reflect = o.cd.pad_reflect; d.relu = o.cd.relu; d.act = o.cd.act;
+                d.stats = stp.fused_stats ? (float*)(ws + stp.aux_off[0]) : nullptr;
+                int phase_idx = 0;
                 for (const PackedPhase& ph : o.phases) {
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
                     d.Kpad = ph.Kpad; d.nk = ph.Kpad / 64;
@@ -564,15 +622,27 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.OHg = d.OH; d.OWg = d.OW; d.sy = d.sx = o.cd.stride; d.osy = d.osx = 1; d.ooy = d.oox = 0;
                     }
                     d.M = n * d.OHg * d.OWg;
+                    d.stats_tile_base = phase_idx * (d.M / 128);
+                    ++phase_idx;
                     rc = gdt_launch_conv(d, st);
                     if (rc != GDT_OK) break;
                 }
+                if (o.rowsplit && rc == GDT_OK)
+                    rc = gdt_k_rowsplit_combine(d.out, o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr,
+                                                (float*)outputs[o.slot], n, d.OH, ti.W, o.rs_cout8, o.cd.cout, o.cd.kw, o.cd.pad,
+                                                o.cd.pad_reflect, o.cd.act, st);
                 break;
             }
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
-                rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), (float*)(ws + stp.aux_off[0]),
-                                         (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, o.relu, st);
+                if (stp.fused_stats)
+                    rc = gdt_k_instance_norm_fused(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out),
+                                                   (const float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
+                                                   (int)net->ops[o.stats_from].phases.size(), (float*)(ws + stp.aux_off[1]), n,
+                                                   ti.H * ti.W, ti.C, o.eps, o.relu, st);
+                else
+                    rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), (float*)(ws + stp.aux_off[0]),
+                                             (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, o.relu, st);
                 break;
             }
             case OP_MAXPOOL: {
