@@ -13,6 +13,8 @@
 // linear per wave-instruction, so the bank-conflict XOR swizzle is applied on the SOURCE chunk index and again on
 // the ds_read_b128 address (chunk' = chunk ^ ((row >> 1) & 7)), which is conflict-free for the 32x32x16 fragment
 // reads.  Two LDS stages, one barrier per K-step: the loads of step k+1 are in flight while step k computes.
+#include <cstdlib>
+
 #include "gdt_common.h"
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -28,11 +30,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
-    static_assert(WGM * WGN == 4, "4 wavefronts per workgroup");
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLaunch d) {
+    constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 wavefronts)
+    constexpr int RPR = NT / 8;                       // tile rows staged per loader round (8 lanes x 16 B per row)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;     // per-wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;       // 32x32 MFMA tiles per wave
-    constexpr int AR = BM / 32, BR = BN / 32;         // loader rounds (32 rows per round for 256 threads)
+    constexpr int AR = BM / RPR, BR = BN / RPR;       // loader rounds
+    static_assert(BM % RPR == 0 && BN % RPR == 0 && RPR % 16 == 0, "tile / workgroup mismatch");
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -52,9 +56,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
         if (tile_m >= ntm) return;   // grid is padded to a multiple of 8 M-tiles
     }
 
-    // ---- per-thread loader state: this thread stages 16-byte chunk (lane & 7) of rows r = round*32 + wave*8 + lane/8
+    // ---- per-thread loader state: this thread stages 16-byte chunk (lane & 7) of rows r = round*RPR + wave*8 + lane/8
     const int lrow = wave * 8 + (lane >> 3);
-    const int swz = (lrow >> 1) & 7;                  // same for every round (round*32 >> 1 is a multiple of 8)
+    const int swz = (lrow >> 1) & 7;                  // same for every round (round*RPR >> 1 is a multiple of 8)
     const int q = (lane & 7) ^ swz;                   // source chunk (8 halves of K) this lane fetches
     const int hw_g = d.OHg * d.OWg;
     int a_base[AR];                                   // pixel index of image n's first pixel (N*H*W < 2^31)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
     unsigned a_valid = 0;                             // bit r: row of round r is inside M
 #pragma unroll
     for (int r = 0; r < AR; ++r) {
-        const int m = tile_m * BM + r * 32 + lrow;
+        const int m = tile_m * BM + r * RPR + lrow;
         const int mm = m < d.M ? m : 0;
         const int n = mm / hw_g, rem = mm - n * hw_g;
         const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
@@ -74,31 +78,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
     const f16* b_src = d.w + ((long)(tile_n * BN + lrow) * d.Kpad + q * 8);
     const int cmask = (1 << d.lc8) - 1;
 
-    auto issue = [&](int ks, int stage) {
-        char* As = smem + stage * A_BYTES;
-        char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
-        // A: decode (tap, channel chunk) of this lane's K chunk
+    // Staging of one K-step is cut into per-round pieces so that the main loop can spread the global_load_lds
+    // instructions (and their address arithmetic) between the MFMAs of the current step instead of issuing them in a burst.
+    int n_dy = 0, n_dx = 0, n_c8 = 0; bool n_tap_ok = false;      // decoded (tap, channel chunk) of the NEXT K-step
+    const bool refl = d.pad_reflect != 0;
+    auto decode = [&](int ks) {
         const int k8 = ks * 8 + q;
-        const int tap = k8 >> d.lc8, c8 = k8 & cmask;
+        const int tap = k8 >> d.lc8;
+        n_c8 = k8 & cmask;
         const int ty = (tap * d.invTW) >> 16, tx = tap - ty * d.TW;
-        const int dy = d.dy0 + ty * d.dys, dx = d.dx0 + tx * d.dxs;
-        const bool tap_ok = tap < d.ntaps;
-        const bool refl = d.pad_reflect != 0;
-#pragma unroll
-        for (int r = 0; r < AR; ++r) {
-            // branch-free padding: compute the reflected index and the in-bounds predicate, select afterwards
-            const int iy = a_iy0[r] + dy, ix = a_ix0[r] + dx;
-            const int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
-            const int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
-            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
-            const bool ok = tap_ok & (((a_valid >> r) & 1u) != 0) & (inb | refl);
-            const int pix = a_base[r] + ry * d.W + rx;       // reflected == identity when in bounds
-            const f16* src = d.in + (((long)pix << (d.lc8 + 3)) + c8 * 8);
-            glds16(ok ? src : d.zeros, As + (r * 32 + wave * 8) * ROWB);
-        }
-#pragma unroll
-        for (int r = 0; r < BR; ++r)
-            glds16(b_src + ((long)r * 32 * d.Kpad + ks * BK), Bs + (r * 32 + wave * 8) * ROWB);
+        n_dy = d.dy0 + ty * d.dys; n_dx = d.dx0 + tx * d.dxs;
+        n_tap_ok = tap < d.ntaps;
+    };
+    auto issue_a = [&](int stage, int r) {
+        char* As = smem + stage * A_BYTES;
+        // branch-free padding: compute the reflected index and the in-bounds predicate, select afterwards
+        const int iy = a_iy0[r] + n_dy, ix = a_ix0[r] + n_dx;
+        const int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+        const int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+        const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+        const bool ok = n_tap_ok & (((a_valid >> r) & 1u) != 0) & (inb | refl);
+        const int pix = a_base[r] + ry * d.W + rx;           // reflected == identity when in bounds
+        const f16* src = d.in + (((long)pix << (d.lc8 + 3)) + n_c8 * 8);
+        glds16(ok ? src : d.zeros, As + (r * RPR + wave * 8) * ROWB);
+    };
+    auto issue_b = [&](int ks, int stage, int r) {
+        char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
+        glds16(b_src + ((long)r * RPR * d.Kpad + ks * BK), Bs + (r * RPR + wave * 8) * ROWB);
     };
 
     f32x16 acc[TM][TN];
@@ -123,25 +129,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
         b_off[j] = row * ROWB; b_sw[j] = (row >> 1) & 7;
     }
 
-    issue(0, 0);
+    decode(0);
+#pragma unroll
+    for (int r = 0; r < AR; ++r) issue_a(0, r);
+#pragma unroll
+    for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
+
+    constexpr int KK = BK / 16;                       // MFMA k-substeps per K-step
+    constexpr int APK = (AR + KK - 1) / KK, BPK = (BR + KK - 1) / KK;   // staging rounds issued per k-substep
+    f16x8 afr[2][TM], bfr[2][TN];                     // fragment double buffer (statically indexed after unrolling)
     for (int ks = 0; ks < d.nk; ++ks) {
         __syncthreads();   // stage ks landed (vmcnt(0) precedes the barrier); everyone is done reading the other stage
-        if (ks + 1 < d.nk) issue(ks + 1, (ks + 1) & 1);
+        const bool more = (ks + 1 < d.nk) && !(d.dbg & 1);
+        const int nst = (ks + 1) & 1;
+        if (more) decode(ks + 1);
         const char* As = smem + (ks & 1) * A_BYTES;
         const char* Bs = smem + 2 * A_BYTES + (ks & 1) * B_BYTES;
+        if (d.dbg & 2) {
+            if (more) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int ch = 2 * kk + fh;
-            f16x8 af[TM], bf[TN];
+                for (int r = 0; r < AR; ++r) issue_a(nst, r);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + a_off[i] + ((ch ^ a_sw[i]) << 4));
+                for (int r = 0; r < BR; ++r) issue_b(ks + 1, nst, r);
+            }
+            continue;
+        }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
+        for (int i = 0; i < TM; ++i) afr[0][i] = *(const f16x8*)(As + a_off[i] + ((fh ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[0][j] = *(const f16x8*)(Bs + b_off[j] + ((fh ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {            // fragments of the next k-substep: in flight while this one's MFMAs run
+                const int ch = 2 * (kk + 1) + fh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) afr[nxt][i] = *(const f16x8*)(As + a_off[i] + ((ch ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
+            }
+            if (more) {
+#pragma unroll
+                for (int r = kk * APK; r < (kk + 1) * APK && r < AR; ++r) issue_a(nst, r);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+                    if (more && i * TN + j == ((TM * TN) / 2 > 0 ? (TM * TN) / 2 - 1 : 0)) {
+#pragma unroll
+                        for (int r = kk * BPK; r < (kk + 1) * BPK && r < BR; ++r) issue_b(ks + 1, nst, r);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -203,21 +244,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
         }
     }
     __syncthreads();
-    if (d.stats && tid < BN) {
+    constexpr int RT = BM / 128;            // 128-row statistics records per tile
+    constexpr int WPR = WGM / RT;           // wave rows per record
+    static_assert(BM % 128 == 0 && WGM % RT == 0 && BN * RT <= NT, "statistics record layout");
+    if (d.stats && tid < BN * RT) {
+        const int rec = tid / BN, col = tid % BN;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WGM; ++w) { s1 += sl[(w * BN + tid) * 2 + 0]; s2 += sl[(w * BN + tid) * 2 + 1]; }
-        const int gcol = tile_n * BN + tid;
+        for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
+        const int gcol = tile_n * BN + col;
         if (gcol < d.Cout) {
-            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m) * 2) * d.Cout + gcol;
+            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
             dst[0] = s1; dst[d.Cout] = s2;
         }
     }
     constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
-    constexpr int NCH = BM * CPR / 256;         // chunks per thread
+    constexpr int NCH = BM * CPR / NT;          // chunks per thread
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int id = c * 256 + tid;
+        const int id = c * NT + tid;
         const int row = id / CPR, c8 = id % CPR;
         const int m = tile_m * BM + row;
         const int col = tile_n * BN + c8 * 8;
@@ -240,13 +285,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvLaunch d) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
+constexpr size_t lds_bytes() {
+    constexpr size_t staging = 2 * (size_t)(BM + BN) * ROWB;
+    constexpr size_t epilogue = ((size_t)BM * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+    return staging > epilogue ? staging : epilogue;
+}
+
+template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     const int ntm = (d.M + BM - 1) / BM, ntn = d.CoutPad / BN;
     const int ntm8 = (ntm + 7) / 8 * 8;
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    static_assert(((size_t)BM * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8 <= 2 * (size_t)(BM + BN) * ROWB,
-                  "epilogue tile + stats scratch must fit the staging LDS");
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(256), lds, stream, d);
+    constexpr size_t lds = lds_bytes<BM, BN, WGM, WGN>();
+    static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;     // one attribute call per template instantiation
+        if (!attr_set) {
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WGM, WGN>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -255,7 +314,10 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
 
 int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
-int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream) {
+int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream) {
+    static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();
+    ConvLaunch d = d_in;
+    d.dbg = dbg;
     GDT_REQUIRE(d.Cin >= 8 && (d.Cin & (d.Cin - 1)) == 0, "Cin must be a power of two >= 8");
     GDT_REQUIRE((1 << d.lc8) * 8 == d.Cin, "lc8 mismatch");
     GDT_REQUIRE(d.Kpad % BK == 0 && d.nk == d.Kpad / BK && d.nk >= 1, "Kpad must be a multiple of 64");
@@ -269,6 +331,15 @@ int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream) {
     if (d.pad_reflect) {
         const int pady = d.dy0 < 0 ? -d.dy0 : 0, padx = d.dx0 < 0 ? -d.dx0 : 0;
         GDT_REQUIRE(pady < d.H && padx < d.W, "reflect padding needs pad < input size");
+    }
+    // large problems: 256-row tiles with 8 wavefronts (half the L2->LDS bytes per FLOP of the 128x128 tile); the grid must
+    // still cover the 256 CUs a few times over
+    const long tiles256 = ((long)d.M + 255) / 256;
+    static const int force_tile = [] { const char* e = getenv("GDT_CONV_TILE"); return e ? atoi(e) : 0; }();   // test knob
+    const long min_blocks = force_tile == 256 ? 1 : 512;
+    if (force_tile != 128) {
+        if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) return launch_cfg<256, 256, 2, 4>(d, stream);
+        if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) return launch_cfg<256, 128, 4, 2>(d, stream);
     }
     if (bn == 128) return launch_cfg<128, 128, 2, 2>(d, stream);
     if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, stream);

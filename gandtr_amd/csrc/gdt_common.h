@@ -60,6 +60,7 @@ struct ConvLaunch {
     int relu;                     // fused ReLU (after bias and residual)
     int act;                      // out_f32 only: 0 none, 1 tanh, 2 sigmoid
     int M;                        // N * OHg * OWg
+    int dbg;                      // timing-only ablation knob (env GDT_CONV_DBG): 1 skip staging loads, 2 skip MFMAs
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
 };
 

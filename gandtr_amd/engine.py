@@ -50,9 +50,12 @@ class HipNet:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h is not None and h.value:
-            self.lib.gdt_net_destroy(h)
-            self.handle = ctypes.c_void_p()
+        if h is not None and h.value and self.lib is not None:
+            try:
+                self.lib.gdt_net_destroy(h)
+            except Exception:       # interpreter shutdown: ctypes may already be torn down
+                pass
+            self.handle = None
 
     # ---- builder -------------------------------------------------------------------------------------------------
     def input(self, channels, perm=None, scale=None, shift=None):
