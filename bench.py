@@ -49,26 +49,36 @@ def timed(fn, steps, warmup, dev, distributed):
     return dt
 
 
+def kernel_name(variant):
+    if variant >= 900000:
+        return "conv3x3_halo_kernel<%d>" % (variant - 900000)
+    return "conv_igemm_kernel<%d,%d>" % (variant // 1000, variant % 1000)
+
+
 def conv_roofline(net, x, steps=3):
-    """Live per-kernel timing (HIP events on the launch stream, recorded inside the library around every op): algorithmic
-    conv FLOPs / duration for the dominant kernel template conv_igemm_kernel<128,128,...>."""
+    """Live per-kernel timing (HIP events on the launch stream, recorded inside the library around every op).  The
+    DOMINANT kernel is the conv kernel variant with the largest share of the step time; achieved = its algorithmic conv
+    FLOPs per launch / its average launch duration."""
     net.set_profiling(True)
-    tot_ms, tot_fl, launches, all_ms = 0.0, 0.0, 0, 0.0
+    per = {}
+    all_ms = 0.0
     for _ in range(steps):
         net.forward(x)
         torch.cuda.synchronize()
-        for kind, tile, ms, fl in net.profile():
+        for kind, variant, ms, fl in net.profile():
             all_ms += ms
-            if kind == 1 and tile == 128:
-                tot_ms += ms
-                tot_fl += fl
-                launches += 1
+            if kind == 1:
+                e = per.setdefault(variant, [0.0, 0.0, 0])
+                e[0] += ms; e[1] += fl; e[2] += 1
     net.set_profiling(False)
+    variant, (tot_ms, tot_fl, launches) = max(per.items(), key=lambda kv: kv[1][0])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_igemm_kernel<128,128,2,2>", "launches_per_step": launches // steps,
-            "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3)}
+            "kernel": kernel_name(variant), "launches_per_step": launches // steps,
+            "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3),
+            "all_conv_kernels": {kernel_name(v): {"ms_per_step": round(e[0] / steps, 3), "tflops": round(e[1] / max(e[0], 1e-9) / 1e9, 1)}
+                                 for v, e in sorted(per.items())}}
 
 
 def host_cores():

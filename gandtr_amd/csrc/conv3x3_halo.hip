@@ -1,0 +1,277 @@
+// 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo tile (gfx950, MI355X).
+//
+// Hot layers: the 18 ResnetBlock convs of the generator (p2p_networks.py:480-494; 88 % of its FLOPs), every VGG16 / HED
+// conv but the first (torchvision cfg "D"; hed.py:50-58) and the stride-1 3x3 convs of the ResNet-101 Bottlenecks.
+//
+// The generic implicit GEMM (conv_igemm.hip) re-stages the A operand for each of the 9 taps, and measures out as bound by
+// the per-CU L2->LDS rate (~50 GB/s), not by MFMA.  Here one workgroup owns a 16x16 output patch of one image (M = 256):
+// per 64-channel chunk it stages the 18x18 input halo ONCE (41.5 KB, padding resolved in the per-lane source address) and
+// runs the 9 taps against it by offsetting the fragment row (halo row = (py+ty)*18 + px+tx); only the weights (BN x 64 per
+// tap) stream every step.  L2->LDS bytes per FLOP drop by ~43 %.
+//   8 wavefronts, v_mfma_f32_32x32x16_f16, two LDS stages for the halo (per chunk) and for the weights (per tap),
+//   one barrier per (chunk, tap) step, weight loads interleaved with the MFMAs, halo rounds spread over taps 0..5 of the
+//   previous chunk.  Same XOR swizzle (chunk' = chunk ^ ((row >> 1) & 7)) and the same epilogue as conv_igemm.hip.
+#include <cstdlib>
+
+#include "gdt_common.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int ROWB = 128;          // bytes per LDS row (64 halves of K)
+constexpr int HALO_W = 18, HALO_ROWS = 324, HALO_ROWS_PAD = 328;
+constexpr int A_BYTES = HALO_ROWS_PAD * ROWB;
+constexpr int NT = 512;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
+}
+
+template <int BN, int WGM, int WGN>
+constexpr size_t halo_lds_bytes() {
+    constexpr size_t staging = 2 * (size_t)A_BYTES + 2 * (size_t)BN * ROWB;
+    constexpr size_t epilogue = ((size_t)256 * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+    return staging > epilogue ? staging : epilogue;
+}
+
+template <int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
+    static_assert(WGM * WGN == 8, "8 wavefronts");
+    constexpr int BM = 256;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BR = BN / 64;                        // weight staging rounds per step (64 rows per round)
+    static_assert(BR >= 1 && TM >= 1 && TN >= 1, "tile shape");
+    constexpr int B_BYTES = BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + 15) >> 4;
+    const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
+    int tile_m, tile_n;
+    {
+        const int b = blockIdx.x;
+        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
+        tile_m = grp * 8 + (rem & 7);
+        tile_n = rem >> 3;
+        if (tile_m >= ntm) return;
+    }
+    const int n = tile_m / tpi, tr = tile_m - n * tpi;
+    const int y0 = (tr / tiles_x) << 4, x0 = (tr % tiles_x) << 4;
+
+    // ---- loader state
+    const int lrow = tid >> 3;                          // 0..63
+    const int swz = (lrow >> 1) & 7;
+    const int q = (lane & 7) ^ swz;
+    const bool refl = d.pad_reflect != 0;
+    int a_pix[6]; unsigned a_ok = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int h = r * 64 + lrow;
+        const int hy = h / HALO_W, hx = h - hy * HALO_W;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+        int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+        ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
+        const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+        a_pix[r] = (n * d.H + ry) * d.W + rx;
+        a_ok |= ((h < HALO_ROWS) & (inb | refl) ? 1u : 0u) << r;
+    }
+    const f16* b_src = d.w + ((long)(tile_n * BN + lrow) * d.Kpad + q * 8);
+
+    auto issue_a = [&](int chunk, int stage, int r) {
+        if (r * 64 + wave * 8 >= HALO_ROWS_PAD) return;            // wave-uniform: rows beyond the padded halo
+        const f16* src = d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + q) * 8);
+        glds16(((a_ok >> r) & 1u) ? src : d.zeros, smem + stage * A_BYTES + (r * 64 + wave * 8) * ROWB);
+    };
+    auto issue_b = [&](int koff, int stage, int r) {
+        glds16(b_src + ((long)r * 64 * d.Kpad + koff), smem + 2 * A_BYTES + stage * B_BYTES + (r * 64 + wave * 8) * ROWB);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    int a_h0[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = wm * WTM + i * 32 + fr;
+        a_h0[i] = (m >> 4) * HALO_W + (m & 15);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + fr;
+        b_off[j] = row * ROWB; b_sw[j] = (row >> 1) & 7;
+    }
+
+    const int nchunks = d.Cin >> 6;
+    const int total = nchunks * 9;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) issue_a(0, 0, r);
+#pragma unroll
+    for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
+
+    f16x8 afr[2][TM], bfr[2][TN];
+    int c = 0, t = 0;                                   // chunk, tap of the current step
+    for (int s = 0; s < total; ++s) {
+        __syncthreads();
+        const bool more = s + 1 < total;
+        int nc = c, nt = t + 1;
+        if (nt == 9) { nt = 0; nc = c + 1; }
+        const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
+        const bool halo_more = (c + 1 < nchunks) && t < 6;
+        const char* As = smem + (c & 1) * A_BYTES;
+        const char* Bs = smem + 2 * A_BYTES + (s & 1) * B_BYTES;
+        const int ty = (t * 21846) >> 16, tx = t - ty * 3;
+        int a_off[TM], a_sw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int h = a_h0[i] + ty * HALO_W + tx;
+            a_off[i] = h * ROWB; a_sw[i] = (h >> 1) & 7;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) afr[0][i] = *(const f16x8*)(As + a_off[i] + ((fh ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[0][j] = *(const f16x8*)(Bs + b_off[j] + ((fh ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < 4) {
+                const int ch = 2 * (kk + 1) + fh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) afr[nxt][i] = *(const f16x8*)(As + a_off[i] + ((ch ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
+            }
+            if (kk == 1 && halo_more) issue_a(c + 1, (c + 1) & 1, t);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+                    if (more && i * TN + j == ((TM * TN) / 2 > 0 ? (TM * TN) / 2 - 1 : 0)) {
+                        if (BR == 4) issue_b(nkoff, (s + 1) & 1, kk);
+                        else if (BR == 2) { if (kk < 2) issue_b(nkoff, (s + 1) & 1, kk); }
+                        else { if (kk == 0) issue_b(nkoff, (s + 1) & 1, 0); }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c = nc; t = nt;
+    }
+
+    // ---------------------------------------------------------------- epilogue (fp16 NHWC through an LDS transpose)
+    constexpr int CP = BN + 8;
+    __syncthreads();
+    f16* Ct = (f16*)smem;
+    const bool relu_now = d.relu && !d.res;
+    constexpr int STATS_OFF = (BM * CP * 2 + 255) / 256 * 256;
+    float* sl = (float*)(smem + STATS_OFF);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + fr;
+        const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float v = acc[i][j][e] + bv;
+                s1 += v; s2 += v * v;
+                if (relu_now) v = fmaxf(v, 0.f);
+                Ct[row * CP + col] = (f16)v;
+            }
+        if (d.stats) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (fh == 0) { sl[(wm * BN + col) * 2 + 0] = s1; sl[(wm * BN + col) * 2 + 1] = s2; }
+        }
+    }
+    __syncthreads();
+    constexpr int WPR = WGM / 2;            // wave rows per 128-row statistics record (2 records per tile)
+    static_assert(WGM % 2 == 0 && BN * 2 <= NT, "statistics record layout");
+    if (d.stats && tid < BN * 2) {
+        const int rec = tid / BN, col = tid % BN;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
+        const int gcol = tile_n * BN + col;
+        if (gcol < d.Cout) {
+            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * 2 + rec) * 2) * d.Cout + gcol;
+            dst[0] = s1; dst[d.Cout] = s2;
+        }
+    }
+    constexpr int CPR = BN / 8, NCH = BM * CPR / NT;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int id = k * NT + tid;
+        const int row = id / CPR, c8 = id % CPR;
+        const int y = y0 + (row >> 4), x = x0 + (row & 15);
+        const int col = tile_n * BN + c8 * 8;
+        if (y >= d.H || x >= d.W || col >= d.Cout) continue;
+        const long off = (((long)n * d.H + y) * d.W + x) * d.Cout + col;
+        f16x8 v = *(const f16x8*)(Ct + row * CP + c8 * 8);
+        if (d.res) {
+            const f16x8 rv = *(const f16x8*)(d.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float tv = (float)v[e] + (float)rv[e];
+                if (d.relu) tv = fmaxf(tv, 0.f);
+                v[e] = (f16)tv;
+            }
+        }
+        *(f16x8*)(d.out + off) = v;
+    }
+}
+
+template <int BN, int WGM, int WGN>
+int launch_halo(const ConvLaunch& d, hipStream_t stream) {
+    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16), ntn = d.CoutPad / BN;
+    const int ntm8 = (tiles + 7) / 8 * 8;
+    constexpr size_t lds = halo_lds_bytes<BN, WGM, WGN>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WGM, WGN>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(NT), lds, stream, d);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+}  // namespace
+
+// Eligibility: 3x3, stride 1, pad 1, Cin a multiple of 64, fp16 NHWC output, enough tiles to fill the chip, and -- when the
+// InstanceNorm statistics are fused -- whole 16x16 patches (H, W multiples of 16) so that the 128-row records line up.
+bool gdt_conv_halo_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 force
+    if (mode == 0) return false;
+    const bool shape = d.ntaps == 9 && d.TW == 3 && d.sy == 1 && d.sx == 1 && d.dy0 == -1 && d.dx0 == -1 && d.dys == 1 && d.dxs == 1 &&
+                       d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Cin % 64 == 0 && !d.out_f32 && d.Cout % 8 == 0 &&
+                       d.OH == d.H && d.OW == d.W && d.Kpad == 9 * d.Cin && d.CoutPad % 64 == 0;
+    if (!shape) return false;
+    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
+    if (mode == 2) return true;
+    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
+    const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
+    // padded patches waste work on ragged sizes: require >= 85 % useful pixels
+    const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
+    return tiles * (d.CoutPad / bn) >= 512 && useful >= 0.85;
+}
+
+int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream) {
+    if (d.CoutPad % 256 == 0) return launch_halo<256, 2, 4>(d, stream);
+    if (d.CoutPad % 128 == 0) return launch_halo<128, 4, 2>(d, stream);
+    return launch_halo<64, 8, 1>(d, stream);
+}

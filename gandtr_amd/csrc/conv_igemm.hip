@@ -314,7 +314,8 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
 
 int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
-int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream) {
+int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
+    int vdummy; if (!variant) variant = &vdummy;
     static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
@@ -328,6 +329,7 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream) {
                              "fused InstanceNorm statistics need whole 128-row tiles per image and a plain conv epilogue");
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
+    if (gdt_conv_halo_eligible(d)) { *variant = 900000 + (d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64)); return gdt_launch_conv_halo(d, stream); }
     if (d.pad_reflect) {
         const int pady = d.dy0 < 0 ? -d.dy0 : 0, padx = d.dx0 < 0 ? -d.dx0 : 0;
         GDT_REQUIRE(pady < d.H && padx < d.W, "reflect padding needs pad < input size");
@@ -338,9 +340,10 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream) {
     static const int force_tile = [] { const char* e = getenv("GDT_CONV_TILE"); return e ? atoi(e) : 0; }();   // test knob
     const long min_blocks = force_tile == 256 ? 1 : 512;
     if (force_tile != 128) {
-        if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) return launch_cfg<256, 256, 2, 4>(d, stream);
-        if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) return launch_cfg<256, 128, 4, 2>(d, stream);
+        if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
+        if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
     }
+    *variant = 128000 + bn;
     if (bn == 128) return launch_cfg<128, 128, 2, 2>(d, stream);
     if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, stream);
     return launch_cfg<128, 32, 4, 1>(d, stream);

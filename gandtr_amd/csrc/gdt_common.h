@@ -64,5 +64,8 @@ struct ConvLaunch {
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
 };
 
-int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream);
+// variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>
+int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
+bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
+int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

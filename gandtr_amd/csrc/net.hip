@@ -114,6 +114,7 @@ struct gdt_net {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     std::vector<double> last_flops;
+    std::vector<int> last_variant;          // kernel variant per conv op (see gdt_launch_conv)
 
     size_t blob_append(const void* data, size_t bytes) {
         const size_t off = align_up(host_blob.size());
@@ -554,7 +555,7 @@ int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int*
         GDT_CHECK_HIP(hipEventSynchronize(net->events[2 * i + 1]));
         GDT_CHECK_HIP(hipEventElapsedTime(&t, net->events[2 * i], net->events[2 * i + 1]));
         kinds[i] = (int)net->ops[i].kind;
-        tile_n[i] = net->ops[i].kind == OP_CONV ? gdt_conv_bn(net->ops[i].cd.cout) : 0;
+        tile_n[i] = net->last_variant[i];
         ms[i] = t;
         flops[i] = net->last_flops[i];
     }
@@ -584,6 +585,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
 
     if (net->profiling) {
         net->last_flops.resize(net->ops.size());
+        net->last_variant.assign(net->ops.size(), 0);
         for (size_t i = 0; i < net->ops.size(); ++i) net->last_flops[i] = op_flops(net, net->ops[i], n, rh, rw);
     }
     for (const Step& stp : plan.steps) {
@@ -624,7 +626,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.M = n * d.OHg * d.OWg;
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
-                    rc = gdt_launch_conv(d, st);
+                    int variant = 0;
+                    rc = gdt_launch_conv(d, st, &variant);
+                    if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;
                 }
                 if (o.rowsplit && rc == GDT_OK)

@@ -115,8 +115,8 @@ int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);
 
 /* Per-op timing for bench.py's roofline line: when enabled, gdt_net_forward records HIP events on the caller's stream
  * around every op.  gdt_net_profile_read (after the forward) returns per op: kind (0 input, 1 conv, 2 instance-norm,
- * 3 maxpool, 4 gem, 5 tap, 6 hed), the conv N-tile (128/64/32: which conv_igemm_kernel template ran), elapsed ms and the
- * algorithmic FLOPs.  No reference counterpart (the reference has wall-clock StopWatch only, mdir/tools/stats.py:48-68). */
+ * 3 maxpool, 4 gem, 5 tap, 6 hed), the conv kernel variant (BM*1000+BN: conv_igemm_kernel<BM,BN>; 900000+BN:
+ * conv3x3_halo_kernel<BN>), elapsed ms and the algorithmic FLOPs.  No reference counterpart (the reference has wall-clock StopWatch only, mdir/tools/stats.py:48-68). */
 int gdt_net_set_profiling(gdt_net* net, int enable);
 int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int* tile_n, double* ms, double* flops);
 

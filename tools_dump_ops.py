@@ -26,5 +26,5 @@ tot = sum(a[2] for a in acc) / 5
 names = {0: "input", 1: "conv", 2: "inorm", 3: "maxpool", 4: "gem", 5: "tap", 6: "hed"}
 for i, (k, t, ms, fl) in enumerate(acc):
     ms /= 5
-    print("%3d %-8s tile %3d  %8.3f ms  %6.1f%%  %8.2f GFLOP  %7.1f TFLOP/s" % (i, names[k], t, ms, 100 * ms / tot, fl / 1e9, fl / ms / 1e9 if ms > 0 else 0))
+    print("%3d %-8s var %6d  %8.3f ms  %6.1f%%  %8.2f GFLOP  %7.1f TFLOP/s" % (i, names[k], t, ms, 100 * ms / tot, fl / 1e9, fl / ms / 1e9 if ms > 0 else 0))
 print("total %.3f ms" % tot)
