@@ -29,6 +29,7 @@ SIGNATURES = {
     "gdt_version": (c_char_p, []),
     "gdt_net_create": (c_int, [POINTER(c_void_p)]),
     "gdt_net_destroy": (None, [c_void_p]),
+    "gdt_net_set_precision": (c_int, [c_void_p, c_int]),
     "gdt_net_input": (c_int, [c_void_p, c_int, _IP, _FP, _FP, _IP]),
     "gdt_net_conv": (c_int, [c_void_p, c_int, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_int, _IP]),

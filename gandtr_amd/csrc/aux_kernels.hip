@@ -17,6 +17,27 @@
 
 namespace {
 
+// activation element access: 8 consecutive channels as fp32, for fp16 (default) and fp32 ("f16x3" precision mode) tensors
+__device__ __forceinline__ void load8(const f16* p, float (&v)[8]) {
+    const f16x8 t = *(const f16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(f16* p, const float (&v)[8]) {
+    f16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+    *(f16x8*)p = t;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -25,28 +46,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ pack_input
 struct PackArgs {
-    const float* x; f16* y;
+    const float* x; void* y;
     int N, C, H, W, OH, OW;
     float rscale;          // 1 / scale_factor (torch's source-index scale when scale_factor is given)
     int resize;
     int perm[8]; float scale[8], shift[8];
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a) {
     const long total = (long)a.N * a.OH * a.OW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ox = (int)(i % a.OW);
         const long t = i / a.OW;
         const int oy = (int)(t % a.OH), n = (int)(t / a.OH);
-        f16x8 o;
+        float o[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (f16)0.f;
+        for (int c = 0; c < 8; ++c) o[c] = 0.f;
         if (!a.resize) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if (c < a.C) {
                     const float v = a.x[(((long)n * a.C + a.perm[c]) * a.H + oy) * a.W + ox];
-                    o[c] = (f16)(v * a.scale[c] + a.shift[c]);
+                    o[c] = v * a.scale[c] + a.shift[c];
                 }
         } else {
             // aten area_pixel_compute_source_index(align_corners=False): src = scale * (dst + 0.5) - 0.5, clamped at 0
@@ -61,16 +83,17 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a) {
                     const float* p = a.x + ((long)n * a.C + a.perm[c]) * a.H * a.W;
                     const float v = ly0 * (lx0 * p[(long)y0 * a.W + x0] + lx1 * p[(long)y0 * a.W + x1]) +
                                     ly1 * (lx0 * p[(long)y1 * a.W + x0] + lx1 * p[(long)y1 * a.W + x1]);
-                    o[c] = (f16)(v * a.scale[c] + a.shift[c]);
+                    o[c] = v * a.scale[c] + a.shift[c];
                 }
         }
-        *(f16x8*)(a.y + i * 8) = o;
+        store8((T*)a.y + i * 8, o);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ InstanceNorm
 // stage 1: per (image, pixel chunk) partial sum / sum of squares for every channel.  partial[n][chunk][2][C]
-__global__ __launch_bounds__(256) void in_stats_kernel(const f16* __restrict__ x, float* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                        int HW, int C, int chunk_px) {
     __shared__ float red[256 * 16];
     const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
@@ -81,11 +104,12 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const f16* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (prow < nprow) {
-        const f16* base = x + ((long)n * HW) * C + c8 * 8;
+        const T* base = x + ((long)n * HW) * C + c8 * 8;
         for (int p = p0 + prow; p < p1; p += nprow) {
-            const f16x8 v = *(const f16x8*)(base + (long)p * C);
+            float v[8];
+            load8(base + (long)p * C, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+            for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
         }
     }
 #pragma unroll
@@ -140,30 +164,32 @@ __global__ __launch_bounds__(256) void in_finalize_tiles_kernel(const float* __r
 }
 
 // stage 3: y = relu?((x - mean) * rstd) (+ residual)
-__global__ __launch_bounds__(256) void in_apply_kernel(const f16* __restrict__ x, const float* __restrict__ mean_rstd,
-                                                       const f16* __restrict__ res, f16* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                       const T* __restrict__ res, T* __restrict__ y,
                                                        long HW, int C, int relu, long total8) {
     const int c8n = C >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c8 = (int)(i % c8n);
         const long n = (i / c8n) / HW;
         const float* mr = mean_rstd + (n * C + c8 * 8) * 2;
-        f16x8 v = *(const f16x8*)(x + i * 8);
-        f16x8 r;
-        if (res) r = *(const f16x8*)(res + i * 8);
+        float v[8], r[8];
+        load8(x + i * 8, v);
+        if (res) load8(res + i * 8, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = ((float)v[e] - mr[2 * e]) * mr[2 * e + 1];
+            float f = (v[e] - mr[2 * e]) * mr[2 * e + 1];
             if (relu) f = fmaxf(f, 0.f);
-            if (res) f += (float)r[e];
-            v[e] = (f16)f;
+            if (res) f += r[e];
+            v[e] = f;
         }
-        *(f16x8*)(y + i * 8) = v;
+        store8(y + i * 8, v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ max pooling
-__global__ __launch_bounds__(256) void maxpool_kernel(const f16* __restrict__ x, f16* __restrict__ y, int N, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
                                                       int C, int OH, int OW, int k, int s, int p) {
     const int c8n = C >> 3;
     const long total = (long)N * OH * OW * c8n;
@@ -172,27 +198,29 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const f16* __restrict__ x,
         long t = i / c8n;
         const int ox = (int)(t % OW); t /= OW;
         const int oy = (int)(t % OH), n = (int)(t / OH);
-        f16x8 m;
+        float m[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-65504.f);
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
         for (int ky = 0; ky < k; ++ky) {
             const int iy = oy * s - p + ky;
             if ((unsigned)iy >= (unsigned)H) continue;
             for (int kx = 0; kx < k; ++kx) {
                 const int ix = ox * s - p + kx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                const f16x8 v = *(const f16x8*)(x + (((long)n * H + iy) * W + ix) * C + c8 * 8);
+                float v[8];
+                load8(x + (((long)n * H + iy) * W + ix) * C + c8 * 8, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
             }
         }
-        *(f16x8*)(y + i * 8) = m;
+        store8(y + i * 8, m);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ GeM + L2N
 // grid (D/64, N); 8 lanes cover 64 channels (16 B each), 32 pixel rows per pass; fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void gem_kernel(const f16* __restrict__ x, float* __restrict__ pooled, int HW, int D,
+template <typename T>
+__global__ __launch_bounds__(256) void gem_kernel(const T* __restrict__ x, float* __restrict__ pooled, int HW, int D,
                                                   float p, float eps) {
     __shared__ float red[32][64];
     const int n = blockIdx.y, d0 = blockIdx.x * 64;
@@ -200,13 +228,14 @@ __global__ __launch_bounds__(256) void gem_kernel(const f16* __restrict__ x, flo
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    const f16* base = x + (long)n * HW * D + d0 + c8 * 8;
+    const T* base = x + (long)n * HW * D + d0 + c8 * 8;
     const bool cube = (p == 3.0f);
     for (int px = prow; px < HW; px += 32) {
-        const f16x8 v = *(const f16x8*)(base + (long)px * D);
+        float v[8];
+        load8(base + (long)px * D, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float f = fmaxf((float)v[e], eps);
+            const float f = fmaxf(v[e], eps);
             s[e] += cube ? f * f * f : powf(f, p);
         }
     }
@@ -268,7 +297,8 @@ __global__ __launch_bounds__(256) void whiten_matvec_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ taps / outputs
-__global__ __launch_bounds__(256) void unpack_output_kernel(const f16* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_output_kernel(const T* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ bias, int N, int HW, int C) {
     const long total = (long)N * C * HW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -284,7 +314,8 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const f16* __restric
 // implicit GEMM computed P[n][y][x'][kx*cout + co] = sum_{ky,c} in[y+ky-pad][x'][c] * W[co][c][ky][kx] (a k x 1 conv with
 // k*cout output channels, so the MFMA N tile is 21/32 used instead of 3/32); this kernel adds the k horizontally shifted
 // partials, the bias and the activation and writes fp32 NCHW.
-__global__ __launch_bounds__(256) void rowsplit_combine_kernel(const f16* __restrict__ P, const float* __restrict__ bias,
+template <typename T>
+__global__ __launch_bounds__(256) void rowsplit_combine_kernel(const T* __restrict__ P, const float* __restrict__ bias,
                                                                float* __restrict__ out, int N, int H, int W, int cp, int cout,
                                                                int kw, int pad, int reflect, int act) {
     const long total = (long)N * H * W;
@@ -296,7 +327,7 @@ __global__ __launch_bounds__(256) void rowsplit_combine_kernel(const f16* __rest
             int xs = x + kx - pad;
             if (reflect) xs = xs < 0 ? -xs : (xs >= W ? 2 * W - 2 - xs : xs);
             else if ((unsigned)xs >= (unsigned)W) continue;
-            const f16* p = P + (row * W + xs) * cp + kx * cout;
+            const T* p = P + (row * W + xs) * cp + kx * cout;
             for (int co = 0; co < cout; ++co) acc[co] += (float)p[co];
         }
         const long n = row / H; const int y = (int)(row % H);
@@ -311,17 +342,19 @@ __global__ __launch_bounds__(256) void rowsplit_combine_kernel(const f16* __rest
 
 // ------------------------------------------------------------------------------------------------ HED head
 // score[n][p] = b + sum_c x[n][p][c] * w[c]; one wavefront per pixel group of 8 (8 lanes per pixel)
-__global__ __launch_bounds__(256) void hed_score_kernel(const f16* __restrict__ x, const float* __restrict__ w, float bias,
+template <typename T>
+__global__ __launch_bounds__(256) void hed_score_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
                                                         float* __restrict__ score, long NP, int C) {
     const long p = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
     const int sub = threadIdx.x & 7;
     float s = 0.f;
     if (p < NP) {
-        const f16* xr = x + p * C;
+        const T* xr = x + p * C;
         for (int c = sub * 8; c < C; c += 64) {
-            const f16x8 v = *(const f16x8*)(xr + c);
+            float v[8];
+            load8(xr + c, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)v[e] * w[c + e];
+            for (int e = 0; e < 8; ++e) s += v[e] * w[c + e];
         }
     }
     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
@@ -367,7 +400,16 @@ inline int grid_for(long work_items, int cap = 256 * 16) {
 }  // namespace
 
 // ================================================================================================ launchers
-int gdt_k_pack_input(const float* x, f16* y, int N, int C, int H, int W, int OH, int OW, float rscale, int resize,
+// `f32` selects the activation element type: 0 = fp16 (default), 1 = fp32 ("f16x3" precision mode).
+#define LAUNCH_T(kernel, f32, grid, lds, st, ...)                                                     \
+    do {                                                                                              \
+        if (f32) hipLaunchKernelGGL(kernel<float>, grid, dim3(256), lds, st, __VA_ARGS__);            \
+        else hipLaunchKernelGGL(kernel<f16>, grid, dim3(256), lds, st, __VA_ARGS__);                  \
+        GDT_CHECK_HIP(hipGetLastError());                                                             \
+    } while (0)
+#define TP(T, p) ((T*)(p))
+
+int gdt_k_pack_input(const float* x, void* y, int f32, int N, int C, int H, int W, int OH, int OW, float rscale, int resize,
                      const int* perm, const float* scale, const float* shift, hipStream_t st) {
     GDT_REQUIRE(C >= 1 && C <= 8, "pack_input supports 1..8 channels");
     PackArgs a;
@@ -377,55 +419,61 @@ int gdt_k_pack_input(const float* x, f16* y, int N, int C, int H, int W, int OH,
         a.scale[c] = (scale && c < C) ? scale[c] : 1.f;
         a.shift[c] = (shift && c < C) ? shift[c] : 0.f;
     }
-    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((long)N * OH * OW)), dim3(256), 0, st, a);
-    GDT_CHECK_HIP(hipGetLastError());
+    LAUNCH_T(pack_input_kernel, f32, dim3(grid_for((long)N * OH * OW)), 0, st, a);
     return GDT_OK;
 }
 
 int gdt_in_stats_chunks(int HW) { int c = (HW + 1023) / 1024; return c < 1 ? 1 : c; }
 
-int gdt_k_instance_norm(const f16* x, const f16* res, f16* y, float* partial, float* mean_rstd, int N, int HW, int C,
-                        float eps, int relu, hipStream_t st) {
-    GDT_REQUIRE(C % 8 == 0 && C <= 2048 && (256 % (C / 8) == 0 || C / 8 > 256), "InstanceNorm channel count");
-    GDT_REQUIRE(C / 8 <= 256, "InstanceNorm supports C <= 2048");
-    const int nchunks = gdt_in_stats_chunks(HW);
-    const int chunk_px = (HW + nchunks - 1) / nchunks;
-    hipLaunchKernelGGL(in_stats_kernel, dim3(nchunks, N), dim3(256), 0, st, x, partial, HW, C, chunk_px);
-    GDT_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, partial, mean_rstd, nchunks, C, HW,
-                       eps, N * C);
-    GDT_CHECK_HIP(hipGetLastError());
+static int launch_apply(const void* x, const void* res, void* y, int f32, const float* mean_rstd, int N, int HW, int C, int relu,
+                        hipStream_t st) {
     const long total8 = (long)N * HW * (C / 8);
-    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, mean_rstd, res, y, (long)HW, C, relu,
-                       total8);
+    if (f32)
+        hipLaunchKernelGGL(in_apply_kernel<float>, dim3(grid_for(total8)), dim3(256), 0, st, (const float*)x, mean_rstd,
+                           (const float*)res, (float*)y, (long)HW, C, relu, total8);
+    else
+        hipLaunchKernelGGL(in_apply_kernel<f16>, dim3(grid_for(total8)), dim3(256), 0, st, (const f16*)x, mean_rstd, (const f16*)res,
+                           (f16*)y, (long)HW, C, relu, total8);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
-int gdt_k_instance_norm_fused(const f16* x, const f16* res, f16* y, const float* tile_partials, int tiles_per_image, int nphase,
-                              float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st) {
+int gdt_k_instance_norm(const void* x, const void* res, void* y, int f32, float* partial, float* mean_rstd, int N, int HW, int C,
+                        float eps, int relu, hipStream_t st) {
+    GDT_REQUIRE(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "InstanceNorm needs a power-of-two channel count <= 2048");
+    const int nchunks = gdt_in_stats_chunks(HW);
+    const int chunk_px = (HW + nchunks - 1) / nchunks;
+    if (f32) hipLaunchKernelGGL(in_stats_kernel<float>, dim3(nchunks, N), dim3(256), 0, st, (const float*)x, partial, HW, C, chunk_px);
+    else hipLaunchKernelGGL(in_stats_kernel<f16>, dim3(nchunks, N), dim3(256), 0, st, (const f16*)x, partial, HW, C, chunk_px);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)partial, mean_rstd, nchunks, C,
+                       HW, eps, N * C);
+    GDT_CHECK_HIP(hipGetLastError());
+    return launch_apply(x, res, y, f32, mean_rstd, N, HW, C, relu, st);
+}
+
+int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, const float* tile_partials, int tiles_per_image,
+                              int nphase, float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st) {
     hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, tile_partials, mean_rstd,
                        tiles_per_image, nphase, N, C, HW, eps);
     GDT_CHECK_HIP(hipGetLastError());
-    const long total8 = (long)N * HW * (C / 8);
-    hipLaunchKernelGGL(in_apply_kernel, dim3(grid_for(total8)), dim3(256), 0, st, x, (const float*)mean_rstd, res, y, (long)HW, C,
-                       relu, total8);
-    GDT_CHECK_HIP(hipGetLastError());
-    return GDT_OK;
+    return launch_apply(x, res, y, f32, mean_rstd, N, HW, C, relu, st);
 }
 
-int gdt_k_maxpool(const f16* x, f16* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
+int gdt_k_maxpool(const void* x, void* y, int f32, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
     GDT_REQUIRE(C % 8 == 0, "maxpool needs C % 8 == 0");
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long)N * OH * OW * (C / 8))), dim3(256), 0, st, x, y, N, H, W, C, OH,
-                       OW, k, s, p);
+    const dim3 grid(grid_for((long)N * OH * OW * (C / 8)));
+    if (f32) hipLaunchKernelGGL(maxpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, k, s, p);
+    else hipLaunchKernelGGL(maxpool_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, (f16*)y, N, H, W, C, OH, OW, k, s, p);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
-int gdt_k_gem_l2n(const f16* x, float* pooled, float* out, int N, int HW, int D, float p, float eps_gem, float eps_l2,
+int gdt_k_gem_l2n(const void* x, int f32, float* pooled, float* out, int N, int HW, int D, float p, float eps_gem, float eps_l2,
                   hipStream_t st) {
     GDT_REQUIRE(D % 64 == 0, "GeM needs D % 64 == 0");
-    hipLaunchKernelGGL(gem_kernel, dim3(D / 64, N), dim3(256), 0, st, x, pooled, HW, D, p, eps_gem);
+    if (f32) hipLaunchKernelGGL(gem_kernel<float>, dim3(D / 64, N), dim3(256), 0, st, (const float*)x, pooled, HW, D, p, eps_gem);
+    else hipLaunchKernelGGL(gem_kernel<f16>, dim3(D / 64, N), dim3(256), 0, st, (const f16*)x, pooled, HW, D, p, eps_gem);
     GDT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)pooled, out, D, eps_l2);
     GDT_CHECK_HIP(hipGetLastError());
@@ -454,24 +502,29 @@ int gdt_k_whiten(const float* P, const float* m, const float* v, float* tmp, flo
     return GDT_OK;
 }
 
-int gdt_k_unpack_output(const f16* x, float* y, const float* bias, int N, int HW, int C, hipStream_t st) {
-    hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, st, x, y, bias, N, HW, C);
+int gdt_k_unpack_output(const void* x, int f32, float* y, const float* bias, int N, int HW, int C, hipStream_t st) {
+    const dim3 grid(grid_for((long)N * HW * C));
+    if (f32) hipLaunchKernelGGL(unpack_output_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, bias, N, HW, C);
+    else hipLaunchKernelGGL(unpack_output_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, y, bias, N, HW, C);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
-int gdt_k_rowsplit_combine(const f16* P, const float* bias, float* out, int N, int H, int W, int cp, int cout, int kw, int pad,
-                           int reflect, int act, hipStream_t st) {
+int gdt_k_rowsplit_combine(const void* P, int f32, const float* bias, float* out, int N, int H, int W, int cp, int cout, int kw,
+                           int pad, int reflect, int act, hipStream_t st) {
     GDT_REQUIRE(cout >= 1 && cout <= 4, "row-split head supports up to 4 output channels");
-    hipLaunchKernelGGL(rowsplit_combine_kernel, dim3(grid_for((long)N * H * W)), dim3(256), 0, st, P, bias, out, N, H, W, cp, cout,
-                       kw, pad, reflect, act);
+    const dim3 grid(grid_for((long)N * H * W));
+    if (f32) hipLaunchKernelGGL(rowsplit_combine_kernel<float>, grid, dim3(256), 0, st, (const float*)P, bias, out, N, H, W, cp, cout, kw, pad, reflect, act);
+    else hipLaunchKernelGGL(rowsplit_combine_kernel<f16>, grid, dim3(256), 0, st, (const f16*)P, bias, out, N, H, W, cp, cout, kw, pad, reflect, act);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
-int gdt_k_hed_score(const f16* x, const float* w, float bias, float* score, long NP, int C, hipStream_t st) {
+int gdt_k_hed_score(const void* x, int f32, const float* w, float bias, float* score, long NP, int C, hipStream_t st) {
     GDT_REQUIRE(C % 8 == 0, "hed_score needs C % 8 == 0");
-    hipLaunchKernelGGL(hed_score_kernel, dim3((int)((NP + 31) / 32)), dim3(256), 0, st, x, w, bias, score, NP, C);
+    const dim3 grid((int)((NP + 31) / 32));
+    if (f32) hipLaunchKernelGGL(hed_score_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, bias, score, NP, C);
+    else hipLaunchKernelGGL(hed_score_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, w, bias, score, NP, C);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

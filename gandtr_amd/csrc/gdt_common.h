@@ -45,6 +45,7 @@ void gdt_set_error(const std::string& msg);
 struct ConvLaunch {
     const f16* in;        // [N][H][W][Cin]
     const f16* w;         // [CoutPad][Kpad]
+    const f16* w_lo;      // f16x3 mode: low parts of the weights, (w - fp16(w)) * 2^11, same layout; else nullptr
     const float* bias;    // [CoutPad] or nullptr
     const f16* res;       // residual, same layout as out, or nullptr
     f16* out;             // [N][OH][OW][Cout]  (nullptr when out_f32 is used)
@@ -68,4 +69,6 @@ struct ConvLaunch {
 int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
+// f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32
+int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

@@ -28,6 +28,7 @@ enum OpKind { OP_INPUT, OP_CONV, OP_INORM, OP_MAXPOOL, OP_GEM, OP_OUT_NCHW, OP_H
 
 struct PackedPhase {
     size_t w_off = 0;                 // byte offset in the device weight blob
+    size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
 };
@@ -110,6 +111,8 @@ struct gdt_net {
     size_t zeros_off = 0;
     bool finalized = false;
     int input_op = -1;
+    int precision = 0;                      // 0: fp16 activations, single MFMA pass; 1: "f16x3" (fp32 activations, split operands)
+    size_t esize() const { return precision ? sizeof(float) : sizeof(f16); }
     // optional per-op timing (bench.py roofline): HIP events recorded on the caller's stream around every op
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -156,7 +159,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         auto set_out = [&](int h, int w) -> int {
             GDT_REQUIRE(h > 0 && w > 0, "layer output would be empty for this input size");
             Tensor& t = T[o.out];
-            t.H = h; t.W = w; t.bytes = (size_t)N * h * w * t.C * sizeof(f16);
+            t.H = h; t.W = w; t.bytes = (size_t)N * h * w * t.C * net->esize();
             t.off = arena.alloc(t.bytes);
             return GDT_OK;
         };
@@ -170,7 +173,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 if (o.out >= 0) rc = set_out(oh, ow);
                 if (o.res >= 0) GDT_REQUIRE(T[o.res].H == oh && T[o.res].W == ow, "residual shape mismatch");
                 if (o.rowsplit) {
-                    const size_t b = (size_t)N * oh * ti.W * o.rs_cout8 * sizeof(f16);
+                    const size_t b = (size_t)N * oh * ti.W * o.rs_cout8 * net->esize();
                     st.aux_off[1] = arena.alloc(b);
                     arena.release(st.aux_off[1], b);
                 }
@@ -273,6 +276,13 @@ int gdt_net_create(gdt_net** net) {
     return GDT_OK;
 }
 
+int gdt_net_set_precision(gdt_net* net, int mode) {
+    GDT_REQUIRE(net && !net->finalized && net->ops.empty(), "precision must be chosen before the first op");
+    GDT_REQUIRE(mode == 0 || mode == 1, "precision mode: 0 = f16, 1 = f16x3");
+    net->precision = mode;
+    return GDT_OK;
+}
+
 void gdt_net_destroy(gdt_net* net) {
     if (!net) return;
     if (net->dev_blob) (void)hipFree(net->dev_blob);
@@ -338,27 +348,41 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
     auto pack = [&](PackedPhase& ph, auto&& wget) {   // wget(cout, c, tap) -> float
         const int K = ph.ntaps * cin_pad;
         ph.Kpad = (K + 63) / 64 * 64;
-        std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f);
+        std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f), pl;
+        if (net->precision) pl.assign(pk.size(), (f16)0.f);
         for (int co = 0; co < cd.cout; ++co)
             for (int t = 0; t < ph.ntaps; ++t)
-                for (int c = 0; c < cd.cin; ++c)
-                    pk[(size_t)co * ph.Kpad + (size_t)t * cin_pad + c] = (f16)(wget(co, c, t) * scale[co]);
+                for (int c = 0; c < cd.cin; ++c) {
+                    const size_t idx = (size_t)co * ph.Kpad + (size_t)t * cin_pad + c;
+                    const float w = wget(co, c, t) * scale[co];
+                    pk[idx] = (f16)w;
+                    if (net->precision) pl[idx] = (f16)((w - (float)pk[idx]) * 2048.f);
+                }
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+        if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
     };
 
     if (o.rowsplit) {
+        // GEMM output channel co' = kx * cout + co, taps = kernel rows
         PackedPhase ph;
         ph.ntaps = cd.kh; ph.TW = 1; ph.dy0 = -cd.pad; ph.dys = 1; ph.dx0 = 0; ph.dxs = 0;
-        const int K = ph.ntaps * cin_pad;
-        ph.Kpad = (K + 63) / 64 * 64;
-        std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f);
-        for (int kx = 0; kx < cd.kw; ++kx)
-            for (int co = 0; co < cd.cout; ++co)
-                for (int ky = 0; ky < cd.kh; ++ky)
-                    for (int c = 0; c < cd.cin; ++c)
-                        pk[(size_t)(kx * cd.cout + co) * ph.Kpad + (size_t)ky * cin_pad + c] =
-                            (f16)weight[(((size_t)co * cd.cin + c) * cd.kh + ky) * cd.kw + kx];
-        ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+        {
+            const int K = ph.ntaps * cin_pad;
+            ph.Kpad = (K + 63) / 64 * 64;
+            std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f), pl;
+            if (net->precision) pl.assign(pk.size(), (f16)0.f);
+            for (int kx = 0; kx < cd.kw; ++kx)
+                for (int co = 0; co < cd.cout; ++co)
+                    for (int ky = 0; ky < cd.kh; ++ky)
+                        for (int c = 0; c < cd.cin; ++c) {
+                            const size_t idx = (size_t)(kx * cd.cout + co) * ph.Kpad + (size_t)ky * cin_pad + c;
+                            const float w = weight[(((size_t)co * cd.cin + c) * cd.kh + ky) * cd.kw + kx];
+                            pk[idx] = (f16)w;
+                            if (net->precision) pl[idx] = (f16)((w - (float)pk[idx]) * 2048.f);
+                        }
+            ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+            if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
+        }
         o.phases.push_back(ph);
     } else if (!cd.transposed) {
         PackedPhase ph;
@@ -580,7 +604,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
     auto& T = net->tensors;
-    auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };
+    auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };      // element type is fp16 or fp32 (net->precision)
+    const int f32 = net->precision;
     const f16* zeros = (const f16*)(net->dev_blob + net->zeros_off);
 
     if (net->profiling) {
@@ -594,7 +619,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
-                rc = gdt_k_pack_input(x, tptr(o.out), n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
+                rc = gdt_k_pack_input(x, tptr(o.out), f32, n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
                 break;
             }
             case OP_CONV: {
@@ -615,7 +640,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 int phase_idx = 0;
                 for (const PackedPhase& ph : o.phases) {
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
-                    d.Kpad = ph.Kpad; d.nk = ph.Kpad / 64;
+                    d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
+                    d.Kpad = ph.Kpad; d.nk = ph.Kpad / (f32 ? 32 : 64);
                     d.ntaps = ph.ntaps; d.TW = ph.TW; d.invTW = (65536 + ph.TW - 1) / ph.TW;
                     d.dy0 = ph.dy0; d.dys = ph.dys; d.dx0 = ph.dx0; d.dxs = ph.dxs;
                     if (o.cd.transposed) {
@@ -627,12 +653,12 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
-                    rc = gdt_launch_conv(d, st, &variant);
+                    rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;
                 }
                 if (o.rowsplit && rc == GDT_OK)
-                    rc = gdt_k_rowsplit_combine(d.out, o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr,
+                    rc = gdt_k_rowsplit_combine(d.out, f32, o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr,
                                                 (float*)outputs[o.slot], n, d.OH, ti.W, o.rs_cout8, o.cd.cout, o.cd.kw, o.cd.pad,
                                                 o.cd.pad_reflect, o.cd.act, st);
                 break;
@@ -640,29 +666,29 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
                 if (stp.fused_stats)
-                    rc = gdt_k_instance_norm_fused(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out),
+                    rc = gdt_k_instance_norm_fused(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), f32,
                                                    (const float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
                                                    (int)net->ops[o.stats_from].phases.size(), (float*)(ws + stp.aux_off[1]), n,
                                                    ti.H * ti.W, ti.C, o.eps, o.relu, st);
                 else
-                    rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), (float*)(ws + stp.aux_off[0]),
+                    rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), f32, (float*)(ws + stp.aux_off[0]),
                                              (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, o.relu, st);
                 break;
             }
             case OP_MAXPOOL: {
                 const Tensor& ti = T[o.in]; const Tensor& to = T[o.out];
-                rc = gdt_k_maxpool(tptr(o.in), tptr(o.out), n, ti.H, ti.W, ti.C, to.H, to.W, o.k, o.s, o.p, st);
+                rc = gdt_k_maxpool(tptr(o.in), tptr(o.out), f32, n, ti.H, ti.W, ti.C, to.H, to.W, o.k, o.s, o.p, st);
                 break;
             }
             case OP_GEM: {
                 const Tensor& ti = T[o.in];
-                rc = gdt_k_gem_l2n(tptr(o.in), (float*)(ws + stp.aux_off[0]), (float*)outputs[o.slot], n, ti.H * ti.W, ti.C, o.gem_p,
+                rc = gdt_k_gem_l2n(tptr(o.in), f32, (float*)(ws + stp.aux_off[0]), (float*)outputs[o.slot], n, ti.H * ti.W, ti.C, o.gem_p,
                                    o.eps_gem, o.eps_l2, st);
                 break;
             }
             case OP_OUT_NCHW: {
                 const Tensor& ti = T[o.in];
-                rc = gdt_k_unpack_output(tptr(o.in), (float*)outputs[o.slot],
+                rc = gdt_k_unpack_output(tptr(o.in), f32, (float*)outputs[o.slot],
                                          o.tap_has_bias ? (const float*)(net->dev_blob + o.tap_bias_off) : nullptr, n, ti.H * ti.W, ti.C, st);
                 break;
             }
@@ -671,7 +697,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 for (int k = 0; k < 5 && rc == GDT_OK; ++k) {
                     const Tensor& tf = T[o.feats[k]];
                     float* s = (float*)(ws + stp.aux_off[k]);
-                    rc = gdt_k_hed_score(tptr(o.feats[k]), (const float*)(net->dev_blob + o.score_w_off[k]), o.score_b[k], s,
+                    rc = gdt_k_hed_score(tptr(o.feats[k]), f32, (const float*)(net->dev_blob + o.score_w_off[k]), o.score_b[k], s,
                                          (long)n * tf.H * tf.W, tf.C, st);
                     sc[k] = s; hh[k] = tf.H; wwv[k] = tf.W;
                 }

@@ -35,8 +35,13 @@ def _ptr(a):
 class HipNet:
     """One layer graph living on one GPU.  Not re-entrant (same rule as the C handle)."""
 
-    def __init__(self, device):
+    PRECISIONS = {"f16": 0, "f16x3": 1}
+
+    def __init__(self, device, precision="f16"):
         self.lib = _hip.load()
+        if precision not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("HipNet needs a cuda (HIP) device, got %s" % self.device)
@@ -44,6 +49,7 @@ class HipNet:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.handle = ctypes.c_void_p()
         _hip.check(self.lib.gdt_net_create(ctypes.byref(self.handle)))
+        _hip.check(self.lib.gdt_net_set_precision(self.handle, self.PRECISIONS[precision]))
         self.in_channels = None
         self._ws = None
         self._finalized = False
@@ -199,14 +205,14 @@ def generator_layout(sd):
     return norm, w0.shape[0], n_blocks, w0.shape[1], sd["model.%d.weight" % last].shape[0]
 
 
-def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None):
+def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precision="f16"):
     """ResnetGenerator as a HIP graph.  External outputs: [generator output] + one per requested tap (in ``taps``
     order).  Taps follow the reference's nn.Sequential indices (p2p_networks.py:316-334); a norm-layer tap aliases the
     post-ReLU tensor because the reference's ReLUs are in-place (:272).  Tap 0 / the second reflection pad are not
     materialised on the device (padding is resolved inside the conv loader) and are not available."""
     norm, ngf, n_blocks, in_nc, out_nc = generator_layout(sd)
     inorm = norm == "instance"
-    net = HipNet(device)
+    net = HipNet(device, precision)
     tap_slots = {}
 
     def tap(idx, t, bias=None):
@@ -302,10 +308,10 @@ def embedder_arch(sd):
     return "resnet" if "features.4.0.conv1.weight" in sd else "vgg16"
 
 
-def build_embedder(sd, device, in_affine=None, feature_tap=False):
+def build_embedder(sd, device, in_affine=None, feature_tap=False, precision="f16"):
     """GeM embedder (ImageRetrievalNet.forward with lwhiten=None, whiten=None).  External output 0: descriptors as a
     row-major [N][D] fp32 matrix (the reference returns its transpose view, D x N)."""
-    net = HipNet(device)
+    net = HipNet(device, precision)
     x = net.input(3, scale=in_affine[0], shift=in_affine[1]) if in_affine is not None else net.input(3)
     f = _resnet_trunk(net, x, sd) if embedder_arch(sd) == "resnet" else _vgg16_trunk(net, x, sd)
     net.out_slot = net.gem_l2n(f, float(sd["pool.p"].reshape(-1)[0]))
@@ -317,10 +323,10 @@ def build_embedder(sd, device, in_affine=None, feature_tap=False):
 HED_BLOCKS = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
 
 
-def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True):
+def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True, precision="f16"):
     """HedInterpolation.forward (hed.py:60-83); ``perm``/``in_affine`` fold the RgbToBgrPre + MeanStdPre wrappers
     (wrapper.py:351-364, :182-194) into the input pack kernel."""
-    net = HipNet(device)
+    net = HipNet(device, precision)
     x = net.input(3, perm=perm, scale=None if in_affine is None else in_affine[0],
                   shift=None if in_affine is None else in_affine[1])
     feats = []

@@ -46,6 +46,13 @@ typedef struct gdt_net gdt_net;
 int gdt_net_create(gdt_net** net);
 void gdt_net_destroy(gdt_net* net);
 
+/* Arithmetic of the conv GEMMs, to be chosen before the first op is added.
+ *   0 "f16"   (default): fp16 NHWC activations, one fp16 MFMA pass, fp32 accumulation (11-bit operands).
+ *   1 "f16x3": fp32 NHWC activations; every operand is split into two fp16 numbers and three MFMA passes are accumulated
+ *              (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): fp32-class accuracy at 3x the matrix work.  Used where the reference's
+ *              fp32 result has to be matched to 1e-3 through deep random-weight stacks. */
+int gdt_net_set_precision(gdt_net* net, int mode);
+
 /* External fp32 NCHW image input with C <= 8 channels (packed to fp16 NHWC8 on entry).  Optional channel permutation
  * (RgbToBgrPre, mdir/components/data/wrapper.py:351-364) and per-channel affine y = x*scale + shift
  * (MeanStdPost/Pre._adapt, wrapper.py:172-175); pass NULL for identity.  A bilinear resize

@@ -121,3 +121,46 @@ def test_hed_on_generator_output(cuda_device):
     got = net.forward(y.to(cuda_device))[net.out_slot].cpu()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- f16x3 precision mode
+@pytest.mark.parametrize("norm,gain", [("instance", 0.02), ("instance", 0.2), ("batch", None)])
+def test_generator_full_f16x3_meets_1e3_everywhere(cuda_device, norm, gain):
+    """north_star's gate (1e-3 rel) at every tap and on the pre-tanh output with the split-fp16 ("f16x3") convolutions."""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, gain=gain or 0.02)
+    x = synth.synth_input(2, (2, 3, 256, 256), 1.0)
+    taps = (1, 3, 9, 10, 14, 18, 21, 24, 26)
+    ref, feats = O.resnet_generator(x, sd, norm, 9, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16x3")
+    outs = net.forward(x.to(cuda_device))
+    for t in taps:
+        r = _rel(outs[net.tap_slots[t]].cpu(), feats[t])
+        assert r < 1e-3, (t, r)
+    if gain != 0.2:
+        assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_tiny_f16x3(cuda_device, norm):
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, ngf=8, n_blocks=2)
+    x = synth.synth_input(1, (2, 3, 32, 32), 1.0)
+    taps = tuple(i for i in range(1, 21) if i != 18)
+    ref, feats = O.resnet_generator(x, sd, norm, 2, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16x3")
+    outs = net.forward(x.to(cuda_device))
+    assert _rel(outs[net.out_slot].cpu(), ref) < 1e-4
+    for t in taps:
+        assert _rel(outs[net.tap_slots[t]].cpu(), feats[t]) < 1e-4, t
+
+
+@pytest.mark.parametrize("arch", ["vgg16", "resnet101"])
+def test_embedder_f16x3(cuda_device, arch):
+    from gandtr_amd.engine import build_embedder
+    sd = synth.vgg16_state(0, p=3.0) if arch == "vgg16" else synth.resnet101_state(0, p=2.37)
+    x = synth.synth_input(3, (2, 3, 160, 192))
+    ref = O.image_retrieval_forward(x, sd, arch).t().contiguous()
+    net = build_embedder(sd, cuda_device, precision="f16x3")
+    got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
+    assert float((got - ref).abs().max()) < 2e-5
