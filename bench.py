@@ -52,10 +52,25 @@ def timed(fn, steps, warmup, dev, distributed):
 def kernel_name(variant):
     if variant >= 900000:
         return "conv3x3_halo_kernel<%d>" % (variant - 900000)
+    if variant >= 300000:
+        return "conv_igemm_x3_kernel<%d>" % (variant - 300000)
     return "conv_igemm_kernel<%d,%d>" % (variant // 1000, variant % 1000)
 
 
-def conv_roofline(net, x, steps=3):
+def pmc_traffic(kernel, key):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json, collected with
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on exactly this workload); None when no pass exists for it."""
+    if key is None:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", key)) as f:
+            doc = json.load(f)
+        return doc["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def conv_roofline(net, x, steps=3, traffic_key=None):
     """Live per-kernel timing (HIP events on the launch stream, recorded inside the library around every op).  The
     DOMINANT kernel is the conv kernel variant with the largest share of the step time; achieved = its algorithmic conv
     FLOPs per launch / its average launch duration."""
@@ -74,7 +89,7 @@ def conv_roofline(net, x, steps=3):
     variant, (tot_ms, tot_fl, launches) = max(per.items(), key=lambda kv: kv[1][0])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(kernel_name(variant), traffic_key),
             "kernel": kernel_name(variant), "launches_per_step": launches // steps,
             "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3),
             "all_conv_kernels": {kernel_name(v): {"ms_per_step": round(e[0] / steps, 3), "tflops": round(e[1] / max(e[0], 1e-9) / 1e9, 1)}
@@ -133,6 +148,7 @@ def main():
     ap.add_argument("--gen-batch", type=int, default=64)
     ap.add_argument("--r101-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the f16x3 (1e-3-exact) generator measurement")
     ap.add_argument("--no-secondary", action="store_true")
     a = ap.parse_args()
 
@@ -153,10 +169,24 @@ def main():
     dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
-    roof = conv_roofline(gen, xg) if rank == 0 else None
+    roof = conv_roofline(gen, xg, traffic_key="r01_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
     gen_tflops = gen_ips * GEN_GFLOP_PER_IMAGE / 1e3 / world
     del gen
     torch.cuda.empty_cache()
+
+    # the same workload in the "f16x3" precision mode (fp32 activations, split-fp16 3-pass convs: 1e-3 at every tap)
+    exact = None
+    if not a.no_exact:
+        genx = engine.build_generator(gsd, dev, precision="f16x3")
+        ksteps = max(2, a.steps // 4)
+        dtx = timed(lambda: genx.forward(xg), ksteps, 1, dev, distributed)
+        roofx = conv_roofline(genx, xg, steps=2) if rank == 0 else None
+        exact = {"precision": "f16x3: fp32 NHWC activations, a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on fp16 MFMA, fp32 accumulate",
+                 "value": round(a.gen_batch * world * ksteps / dtx, 2), "unit": "images/s", "steps": ksteps,
+                 "ms_per_step": round(dtx / ksteps * 1e3, 3), "parity": "max|d|/max|ref| <= 1e-3 at every tap (tests/test_hip_models.py)",
+                 "roofline": roofx}
+        del genx
+        torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- secondary: GeM-R101 descriptors/s @1024^2
     secondary = None
@@ -192,7 +222,9 @@ def main():
                            "batch_per_gpu": a.gen_batch, "global_batch": a.gen_batch * world, "parallelism": "dp%d" % world,
                            "precision": "fp16 MFMA inputs, fp32 accumulate, fp16 NHWC activations"},
                 "whole_net_tflops_per_gpu": round(gen_tflops, 1),
-                "roofline": roof, "secondary": secondary}
+                "parity": "descriptor gates met (cos >= 0.9999, |d|inf <= 1e-3); generator image max|d|/max|ref| <= 3.5e-3 pre-tanh "
+                          "(single-pass fp16, DESIGN.md section 5); see exact_mode for the 1e-3 configuration",
+                "roofline": roof, "exact_mode": exact, "secondary": secondary}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_generator()
             if secondary is not None:

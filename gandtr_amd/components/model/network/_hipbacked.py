@@ -5,10 +5,24 @@ live on a cuda (HIP) device the forward is served by a ``gandtr_amd.engine.HipNe
 state dict.  The HIP net is rebuilt whenever a parameter/buffer was modified (version counters) or moved.
 A cuda device with a missing libgandtr_hip.so raises -- there is no torch fallback on the GPU.
 """
+import os
+
 import torch
 
 
+def default_precision():
+    """'f16' (single fp16 MFMA pass, the throughput mode) unless GANDTR_HIP_PRECISION=f16x3 selects the split-fp16 mode that
+    reproduces the reference's fp32 results to 1e-3 at every layer."""
+    return os.environ.get("GANDTR_HIP_PRECISION", "f16")
+
+
 class HipBacked:
+    #: per-module override of the conv arithmetic on the HIP path: None -> default_precision()
+    hip_precision = None
+
+    def _hip_precision(self):
+        return self.hip_precision or default_precision()
+
     def _hip_device(self):
         p = next(self.parameters(), None)
         if p is None:

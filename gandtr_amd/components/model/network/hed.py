@@ -35,7 +35,9 @@ class HedInterpolation(HipBacked, nn.Module):
     def forward(self, x, no_sigmoid=False):
         if self._hip_device().type == "cuda":
             from .... import engine
-            net = self._hip_net(("hed", bool(no_sigmoid)), lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid))
+            prec = self._hip_precision()
+            net = self._hip_net(("hed", bool(no_sigmoid), prec),
+                                lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid, precision=prec))
             return net.forward(x)[net.out_slot]
         size = (x.size(2), x.size(3))
         feats, h = [], x

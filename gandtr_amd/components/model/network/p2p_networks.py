@@ -120,7 +120,8 @@ class ResnetGenerator(HipBacked, nn.Module):
         unavailable = [t for t in taps if t in (0, last - 2)]
         if unavailable:
             raise NotImplementedError("feature taps %s (reflection-padded tensors) are not materialised on the HIP path" % unavailable)
-        net = self._hip_net(("gen", taps), lambda sd, dev: engine.build_generator(sd, dev, taps=taps))
+        prec = self._hip_precision()
+        net = self._hip_net(("gen", taps, prec), lambda sd, dev: engine.build_generator(sd, dev, taps=taps, precision=prec))
         outs = net.forward(x)
         out = outs[net.out_slot]
         if not layers:

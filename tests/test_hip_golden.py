@@ -130,3 +130,17 @@ def test_chain_config5_on_gpu(cuda_device):
     assert d.shape == ref.shape
     assert float(torch.nn.functional.cosine_similarity(d.cpu().t(), ref.t(), dim=1).min()) > 0.9999
     assert float((d.cpu() - ref).abs().max()) < 1e-3
+
+
+def test_hub_generator_precision_switch(cuda_device, monkeypatch):
+    """GANDTR_HIP_PRECISION / Module.hip_precision select the f16x3 mode on the hub path; it must be closer to the reference"""
+    g = load("hub_cyclegan")
+    ref = torch.from_numpy(g["out_sub"])
+    x = synth.synth_input(3, (4, 3, 256, 256), 1.0)
+    net = hubconf.cyclegan(pretrained=False, device=cuda_device)
+    with torch.no_grad():
+        fast = net(x).cpu()[:, :, ::8, ::8]
+        net.model.hip_precision = "f16x3"
+        exact = net(x).cpu()[:, :, ::8, ::8]
+    e_fast, e_exact = float((fast - ref).abs().mean()), float((exact - ref).abs().mean())
+    assert e_exact < 2e-5 and e_exact < e_fast / 20, (e_fast, e_exact)

@@ -6,15 +6,16 @@ from gandtr_amd import engine
 from gandtr_amd.tools import synth
 
 which = sys.argv[1] if len(sys.argv) > 1 else "gen"
+prec = sys.argv[2] if len(sys.argv) > 2 else "f16"
 dev = torch.device("cuda:0")
 if which == "gen":
-    net = engine.build_generator(synth.generator_state(0, "instance"), dev); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
+    net = engine.build_generator(synth.generator_state(0, "instance"), dev, precision=prec); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
 elif which == "genbn":
-    net = engine.build_generator(synth.generator_state(0, "batch"), dev); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
+    net = engine.build_generator(synth.generator_state(0, "batch"), dev, precision=prec); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
 elif which == "r101":
-    net = engine.build_embedder(synth.resnet101_state(0), dev); x = synth.synth_input(1, (16, 3, 1024, 1024)).to(dev)
+    net = engine.build_embedder(synth.resnet101_state(0), dev, precision=prec); x = synth.synth_input(1, (16, 3, 1024, 1024)).to(dev)
 else:
-    net = engine.build_embedder(synth.vgg16_state(0), dev); x = synth.synth_input(1, (8, 3, 1024, 1024)).to(dev)
+    net = engine.build_embedder(synth.vgg16_state(0), dev, precision=prec); x = synth.synth_input(1, (8, 3, 1024, 1024)).to(dev)
 for _ in range(3): net.forward(x)
 net.set_profiling(True)
 acc = None
