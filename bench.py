@@ -50,6 +50,8 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 930000:
+        return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
     if variant >= 900000:
         return "conv3x3_halo_kernel<%d>" % (variant - 900000)
     if variant >= 300000:
@@ -141,6 +143,11 @@ def cpu_baseline_r101(seconds=10.0):
 
 
 def main():
+    # RCCL prints a version banner to stdout on first use; the driver expects exactly one JSON line there, so everything
+    # but the final line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -155,7 +162,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("GANDTR_BENCH_FORCE_DIST") == "1"    # the latter: exercise the RCCL path on one GPU
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -229,7 +236,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline_generator()
             if secondary is not None:
                 secondary["cpu_baseline"] = cpu_baseline_r101()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

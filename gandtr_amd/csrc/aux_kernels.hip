@@ -146,21 +146,31 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
 // tile index = phase * (N * tpi) + n * tpi + t   (phases: 1 for Conv2d, 4 for the ConvTranspose2d sub-pixel launches)
 __global__ __launch_bounds__(256) void in_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
                                                                 int tpi, int nphase, int N, int C, int HW, float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i % C;
+    // grid (C / 64, N): 64 channels x 4 record lanes per workgroup; records are strided over the 4 lanes and merged in a
+    // fixed order (fp64), so the result does not depend on scheduling
+    __shared__ double red[2][4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lanegrp = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    for (int ph = 0; ph < nphase; ++ph)
-        for (int t = 0; t < tpi; ++t) {
+    if (c < C) {
+        const int nrec = nphase * tpi;
+        for (int r = lanegrp; r < nrec; r += 4) {
+            const int ph = r / tpi, t = r - ph * tpi;
             const long tile = (long)ph * N * tpi + (long)n * tpi + t;
             s += (double)partial[(tile * 2 + 0) * C + c];
             q += (double)partial[(tile * 2 + 1) * C + c];
         }
-    const double m = s / HW;
-    double var = q / HW - m * m;
-    var = var < 0.0 ? 0.0 : var;
-    mean_rstd[(long)i * 2 + 0] = (float)m;
-    mean_rstd[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    red[0][lanegrp][threadIdx.x & 63] = s; red[1][lanegrp][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        s = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+        q = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        const double m = s / HW;
+        double var = q / HW - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean_rstd[((long)n * C + c) * 2 + 0] = (float)m;
+        mean_rstd[((long)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // stage 3: y = relu?((x - mean) * rstd) (+ residual)
@@ -454,7 +464,7 @@ int gdt_k_instance_norm(const void* x, const void* res, void* y, int f32, float*
 
 int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, const float* tile_partials, int tiles_per_image,
                               int nphase, float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st) {
-    hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, tile_partials, mean_rstd,
+    hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, tile_partials, mean_rstd,
                        tiles_per_image, nphase, N, C, HW, eps);
     GDT_CHECK_HIP(hipGetLastError());
     return launch_apply(x, res, y, f32, mean_rstd, N, HW, C, relu, st);

@@ -255,6 +255,8 @@ int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant) {
     }
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
+    if (gdt_conv_halo_x3_eligible(d)) { if (variant) *variant = 930128; return gdt_launch_conv_halo_x3(d, stream); }
+    GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");
     if (variant) *variant = 300000 + bn;
     if (bn == 128) return launch_x3<128, 2, 2>(d, stream);
     if (bn == 64) return launch_x3<64, 2, 2>(d, stream);

@@ -52,6 +52,8 @@ struct ConvLaunch {
     float* out_f32;       // [N][Cout][OH][OW] fp32 NCHW, or nullptr
     float* stats;         // per-tile partial sums [tiles][2][Cout] (sum, sum of squares) for InstanceNorm, or nullptr
     const f16* zeros;     // >= 16 B of zeros (source for padded / out-of-range chunks)
+    const float* in_norm; // optional fused InstanceNorm of the INPUT: (mean, rstd) pairs [N][Cin][2], applied while staging A
+    int in_relu;          // ... followed by ReLU
     int N, H, W, Cin, lc8;        // lc8 = log2(Cin / 8)
     int Cout, CoutPad, Kpad, nk;  // nk = Kpad / 64
     int OHg, OWg, OH, OW;         // output grid of this launch, full output size
@@ -71,4 +73,6 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32
 int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
+bool gdt_conv_halo_x3_eligible(const ConvLaunch& d);       // conv3x3_halo_x3.hip
+int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream);
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)
