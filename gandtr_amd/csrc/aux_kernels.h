@@ -10,6 +10,8 @@ int gdt_k_instance_norm(const void* x, const void* res, void* y, int f32, float*
                         float eps, int relu, hipStream_t st);
 int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, const float* tile_partials, int tiles_per_image,
                               int nphase, float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st);
+int gdt_k_instance_norm_stats(const void* x, int f32, int fused, float* partial, int tiles_per_image, int nphase, float* mean_rstd,
+                              int N, int HW, int C, float eps, hipStream_t st);
 int gdt_k_maxpool(const void* x, void* y, int f32, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st);
 int gdt_k_gem_l2n(const void* x, int f32, float* pooled, float* out, int N, int HW, int D, float p, float eps_gem, float eps_l2,
                   hipStream_t st);

@@ -470,6 +470,27 @@ int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, 
     return launch_apply(x, res, y, f32, mean_rstd, N, HW, C, relu, st);
 }
 
+// mean / rstd only (the normalisation itself is applied by the consuming conv's input staging)
+int gdt_k_instance_norm_stats(const void* x, int f32, int fused, float* partial, int tiles_per_image, int nphase, float* mean_rstd,
+                              int N, int HW, int C, float eps, hipStream_t st) {
+    if (fused) {
+        hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const float*)partial, mean_rstd,
+                           tiles_per_image, nphase, N, C, HW, eps);
+        GDT_CHECK_HIP(hipGetLastError());
+        return GDT_OK;
+    }
+    GDT_REQUIRE(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "InstanceNorm needs a power-of-two channel count <= 2048");
+    const int nchunks = gdt_in_stats_chunks(HW);
+    const int chunk_px = (HW + nchunks - 1) / nchunks;
+    if (f32) hipLaunchKernelGGL(in_stats_kernel<float>, dim3(nchunks, N), dim3(256), 0, st, (const float*)x, partial, HW, C, chunk_px);
+    else hipLaunchKernelGGL(in_stats_kernel<f16>, dim3(nchunks, N), dim3(256), 0, st, (const f16*)x, partial, HW, C, chunk_px);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const float*)partial, mean_rstd, nchunks, C,
+                       HW, eps, N * C);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
 int gdt_k_maxpool(const void* x, void* y, int f32, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
     GDT_REQUIRE(C % 8 == 0, "maxpool needs C % 8 == 0");
     const dim3 grid(grid_for((long)N * OH * OW * (C / 8)));

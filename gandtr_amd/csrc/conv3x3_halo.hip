@@ -88,6 +88,37 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         const f16* src = d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + q) * 8);
         glds16(((a_ok >> r) & 1u) ? src : d.zeros, smem + stage * A_BYTES + (r * 64 + wave * 8) * ROWB);
     };
+    // Fused InstanceNorm (+ReLU) of the producer (p2p_networks.py:29,:272): when d.in_norm is set the halo goes through
+    // registers instead -- load 8 raw fp16 channels, x -> max((x - mean) * rstd, 0) in fp32, store to the same swizzled LDS
+    // slot the DMA path would have filled.  One piece per tap step, written one step after it was issued.
+    const bool norm_a = d.in_norm != nullptr;     // wave-uniform
+    float nmr[16];                                // (mean, rstd) of this lane's 8 channels in the chunk being staged
+    auto load_norm = [&](int chunk) {
+        const float4* p = (const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64 + q * 8) * 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float4 v = p[k]; nmr[4 * k] = v.x; nmr[4 * k + 1] = v.y; nmr[4 * k + 2] = v.z; nmr[4 * k + 3] = v.w; }
+    };
+    auto load_piece = [&](int chunk, int r) -> f16x8 {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+        if (r * 64 + lrow < HALO_ROWS_PAD && ((a_ok >> r) & 1u))
+            v = *(const f16x8*)(d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + q) * 8));
+        return v;
+    };
+    auto store_piece = [&](int stage, int r, const f16x8& raw) {
+        const int row = r * 64 + lrow;
+        if (row >= HALO_ROWS_PAD) return;
+        f16x8 o;
+        const bool ok = (a_ok >> r) & 1u;                      // padded positions stay exactly zero
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = ((float)raw[e] - nmr[2 * e]) * nmr[2 * e + 1];
+            if (d.in_relu) f = fmaxf(f, 0.f);
+            o[e] = ok ? (f16)f : (f16)0.f;
+        }
+        *(f16x8*)(smem + stage * A_BYTES + row * ROWB + ((lane & 7) << 4)) = o;
+    };
     auto issue_b = [&](int koff, int stage, int r) {
         glds16(b_src + ((long)r * 64 * d.Kpad + koff), smem + 2 * A_BYTES + stage * B_BYTES + (r * 64 + wave * 8) * ROWB);
     };
@@ -115,20 +146,35 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
 
     const int nchunks = d.Cin >> 6;
     const int total = nchunks * 9;
+    if (norm_a) {
+        load_norm(0);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) issue_a(0, 0, r);
+        for (int r = 0; r < 6; ++r) store_piece(0, r, load_piece(0, r));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) issue_a(0, 0, r);
+    }
 #pragma unroll
     for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
+    f16x8 pend;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pend[e] = (f16)0.f;
 
     f16x8 afr[2][TM], bfr[2][TN];
     int c = 0, t = 0;                                   // chunk, tap of the current step
     for (int s = 0; s < total; ++s) {
         __syncthreads();
-        const bool more = s + 1 < total;
+        const bool more = (s + 1 < total) && !(d.dbg & 1);
         int nc = c, nt = t + 1;
         if (nt == 9) { nt = 0; nc = c + 1; }
         const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
-        const bool halo_more = (c + 1 < nchunks) && t < 6;
+        const bool halo_more = (c + 1 < nchunks) && t < 6 && !norm_a;
+        if (norm_a && c + 1 < nchunks) {
+            // nmr holds chunk c+1's statistics from tap 0 on: every piece of chunk c+1 is normalised with them
+            if (t >= 1 && t <= 6) store_piece((c + 1) & 1, t - 1, pend);
+            if (t == 0) load_norm(c + 1);
+            if (t < 6) pend = load_piece(c + 1, t);
+        }
         const char* As = smem + (c & 1) * A_BYTES;
         const char* Bs = smem + 2 * A_BYTES + (s & 1) * B_BYTES;
         const int ty = (t * 21846) >> 16, tx = t - ty * 3;
@@ -142,6 +188,15 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         for (int i = 0; i < TM; ++i) afr[0][i] = *(const f16x8*)(As + a_off[i] + ((fh ^ a_sw[i]) << 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[0][j] = *(const f16x8*)(Bs + b_off[j] + ((fh ^ b_sw[j]) << 4));
+        if (d.dbg & 2) {       // timing-only ablation: staging without MFMAs
+            if (halo_more) issue_a(c + 1, (c + 1) & 1, t);
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < BR; ++r) issue_b(nkoff, (s + 1) & 1, r);
+            }
+            c = nc; t = nt;
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
@@ -270,7 +325,10 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d) {
     return tiles * (d.CoutPad / bn) >= 512 && useful >= 0.85;
 }
 
-int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream) {
+int gdt_launch_conv_halo(const ConvLaunch& d_in, hipStream_t stream) {
+    static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();
+    ConvLaunch d = d_in;
+    d.dbg = dbg;
     if (d.CoutPad % 256 == 0) return launch_halo<256, 2, 4>(d, stream);
     if (d.CoutPad % 128 == 0) return launch_halo<128, 4, 2>(d, stream);
     return launch_halo<64, 8, 1>(d, stream);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 }
 
 __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d) {
-    constexpr int WGM = 4, WGN = 2, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int WGN = 2, WTM = 64, WTN = 64, TM = 2, TN = 2;      // 4 x 2 wavefronts, 64 x 64 per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][A hi, A lo] [2][B hi, B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;

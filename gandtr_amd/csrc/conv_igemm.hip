@@ -339,10 +339,11 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     const long tiles256 = ((long)d.M + 255) / 256;
     static const int force_tile = [] { const char* e = getenv("GDT_CONV_TILE"); return e ? atoi(e) : 0; }();   // test knob
     const long min_blocks = force_tile == 256 ? 1 : 512;
-    if (force_tile != 128) {
+    if (force_tile != 128 && !d.in_norm) {
         if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
         if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
     }
+    GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");
     *variant = 128000 + bn;
     if (bn == 128) return launch_cfg<128, 128, 2, 2>(d, stream);
     if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, stream);

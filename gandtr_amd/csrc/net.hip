@@ -6,6 +6,7 @@
 // liveness-based workspace layout and launches the HIP kernels on the caller's stream.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -131,7 +132,11 @@ struct gdt_net {
 
 namespace {
 
-struct Step { int op; size_t aux_off[8]; bool fused_stats; int tiles_per_image; };
+struct Step {
+    int op; size_t aux_off[8]; bool fused_stats; int tiles_per_image;
+    int norm_into;   // INORM: index of the conv op that applies this normalisation while staging its input (-1: own apply pass)
+    int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
+};
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
 
 int conv_out_dim(const gdt_conv_desc& c, int in, int k) {
@@ -139,61 +144,132 @@ int conv_out_dim(const gdt_conv_desc& c, int in, int k) {
     return (in + 2 * c.pad - k) / c.stride + 1;
 }
 
-// shape inference + workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
+// geometry part of a conv launch (everything but the pointers) for one phase of op `o` reading a tensor of size ti
+void conv_geometry(const gdt_net* net, const Op& o, const PackedPhase& ph, int n, const Tensor& ti, ConvLaunch& d) {
+    d.N = n; d.H = ti.H; d.W = ti.W; d.Cin = o.cin_pad; d.lc8 = ilog2(o.cin_pad / 8);
+    d.Cout = o.cd.cout; d.CoutPad = o.cout_pad;
+    d.OH = conv_out_dim(o.cd, ti.H, o.cd.kh); d.OW = conv_out_dim(o.cd, ti.W, o.cd.kw);
+    d.pad_reflect = o.cd.pad_reflect; d.relu = o.cd.relu; d.act = o.cd.act;
+    d.Kpad = ph.Kpad; d.nk = ph.Kpad / (net->precision ? 32 : 64);
+    d.ntaps = ph.ntaps; d.TW = ph.TW; d.invTW = (65536 + ph.TW - 1) / ph.TW;
+    d.dy0 = ph.dy0; d.dys = ph.dys; d.dx0 = ph.dx0; d.dxs = ph.dxs;
+    if (o.cd.transposed) {
+        d.OHg = ti.H; d.OWg = ti.W; d.sy = d.sx = 1; d.osy = d.osx = 2; d.ooy = ph.ooy; d.oox = ph.oox;
+    } else {
+        d.OHg = d.OH; d.OWg = d.OW; d.sy = d.sx = o.cd.stride; d.osy = d.osx = 1; d.ooy = d.oox = 0;
+    }
+    d.M = n * d.OHg * d.OWg;
+}
+
+bool conv_fuses_stats(const Op& o, const Tensor& ti) {      // InstanceNorm partial statistics from the conv epilogue
+    if (o.stats_for < 0 || o.cd.relu || o.res >= 0) return false;
+    const int hwg = o.cd.transposed ? ti.H * ti.W : conv_out_dim(o.cd, ti.H, o.cd.kh) * conv_out_dim(o.cd, ti.W, o.cd.kw);
+    return hwg % 128 == 0;
+}
+
+// shape inference, fusion decisions and workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
 int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     auto& T = net->tensors;
+    const auto& ops = net->ops;
+    const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
-    // last uses
-    for (size_t i = 0; i < net->ops.size(); ++i) {
-        const Op& o = net->ops[i];
-        if (o.in >= 0) T[o.in].last_use = (int)i;
-        if (o.res >= 0) T[o.res].last_use = (int)i;
-        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = (int)i;
-    }
-    Arena arena;
-    plan.steps.clear();
-    std::vector<size_t> slab_off(net->ops.size(), 0), slab_bytes(net->ops.size(), 0);
-    for (size_t i = 0; i < net->ops.size(); ++i) {
-        const Op& o = net->ops[i];
-        Step st{}; st.op = (int)i;
-        auto set_out = [&](int h, int w) -> int {
-            GDT_REQUIRE(h > 0 && w > 0, "layer output would be empty for this input size");
-            Tensor& t = T[o.out];
-            t.H = h; t.W = w; t.bytes = (size_t)N * h * w * t.C * net->esize();
-            t.off = arena.alloc(t.bytes);
-            return GDT_OK;
-        };
-        int rc = GDT_OK;
+    plan.steps.assign(nops, Step{});
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; }
+
+    // ---- pass 1: shapes
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        int h = 0, w = 0;
         switch (o.kind) {
-            case OP_INPUT: rc = set_out(RH, RW); break;
+            case OP_INPUT: h = RH; w = RW; break;
             case OP_CONV: {
                 const Tensor& ti = T[o.in];
-                const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh), ow = conv_out_dim(o.cd, ti.W, o.cd.kw);
+                h = conv_out_dim(o.cd, ti.H, o.cd.kh); w = conv_out_dim(o.cd, ti.W, o.cd.kw);
                 if (o.cd.pad_reflect) GDT_REQUIRE(o.cd.pad < ti.H && o.cd.pad < ti.W, "reflection padding needs pad < input size");
-                if (o.out >= 0) rc = set_out(oh, ow);
-                if (o.res >= 0) GDT_REQUIRE(T[o.res].H == oh && T[o.res].W == ow, "residual shape mismatch");
+                GDT_REQUIRE(h > 0 && w > 0, "layer output would be empty for this input size");
+                if (o.res >= 0) GDT_REQUIRE(T[o.res].H == h && T[o.res].W == w, "residual shape mismatch");
+                break;
+            }
+            case OP_INORM: h = T[o.in].H; w = T[o.in].W; break;
+            case OP_MAXPOOL: h = (T[o.in].H + 2 * o.p - o.k) / o.s + 1; w = (T[o.in].W + 2 * o.p - o.k) / o.s + 1; break;
+            default: break;
+        }
+        if (o.out >= 0) {
+            GDT_REQUIRE(h > 0 && w > 0, "layer output would be empty for this input size");
+            T[o.out].H = h; T[o.out].W = w;
+        }
+    }
+
+    // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
+    static const bool allow_norm_fusion = [] { const char* e = getenv("GDT_NORM_FUSION"); return !e || atoi(e) != 0; }();
+    std::vector<int> consumers(T.size(), 0), consumer_op(T.size(), -1);
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        auto use = [&](int t) { if (t >= 0) { ++consumers[t]; consumer_op[t] = i; } };
+        use(o.in); use(o.res);
+        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) use(o.feats[k]);
+    }
+    for (int j = 0; j < nops && allow_norm_fusion; ++j) {
+        const Op& oj = ops[j];
+        if (oj.kind != OP_INORM || oj.res >= 0 || consumers[oj.out] != 1 || net->precision) continue;   // f16x3: measured neutral
+
+        const int k = consumer_op[oj.out];
+        const Op& ok = ops[k];
+        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || ok.rowsplit || ok.cd.transposed || ok.cd.out_f32_nchw) continue;
+        ConvLaunch d{};
+        conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
+        d.w_lo = net->precision ? (const f16*)net : nullptr;                       // non-null marker only
+        d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
+        const bool halo = net->precision ? gdt_conv_halo_x3_eligible(d) : gdt_conv_halo_eligible(d);
+        if (halo) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; }
+    }
+
+    // ---- pass 3: liveness + first-fit layout
+    auto conv_input = [&](int i) { return plan.steps[i].norm_from >= 0 ? ops[plan.steps[i].norm_from].in : ops[i].in; };
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        const int in = o.kind == OP_CONV ? conv_input(i) : o.in;
+        if (in >= 0) T[in].last_use = i;
+        if (o.res >= 0) T[o.res].last_use = i;
+        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = i;
+    }
+    Arena arena;
+    std::vector<size_t> slab_off(nops, 0), slab_bytes(nops, 0);
+    std::vector<std::vector<std::pair<size_t, size_t>>> deferred(nops);      // releases to perform after op i
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        Step& st = plan.steps[i];
+        auto alloc_out = [&]() {
+            Tensor& t = T[o.out];
+            t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
+            t.off = arena.alloc(t.bytes);
+        };
+        switch (o.kind) {
+            case OP_INPUT: alloc_out(); break;
+            case OP_CONV: {
+                const Tensor& ti = T[o.in];       // same size as the raw tensor when the norm is folded
+                const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh);
+                if (o.out >= 0) alloc_out();
                 if (o.rowsplit) {
                     const size_t b = (size_t)N * oh * ti.W * o.rs_cout8 * net->esize();
                     st.aux_off[1] = arena.alloc(b);
                     arena.release(st.aux_off[1], b);
                 }
-                if (o.stats_for >= 0 && rc == GDT_OK) {
-                    // fused InstanceNorm statistics: possible when every 128-row tile lies inside one image
-                    const int hwg = o.cd.transposed ? ti.H * ti.W : oh * ow;
-                    if (hwg % 128 == 0 && !o.cd.relu && o.res < 0) {
-                        const size_t tiles = (size_t)o.phases.size() * N * (hwg / 128);
-                        st.fused_stats = true; st.tiles_per_image = hwg / 128;
-                        slab_bytes[i] = tiles * 2 * o.cd.cout * sizeof(float);
-                        st.aux_off[0] = arena.alloc(slab_bytes[i]);
-                        slab_off[i] = st.aux_off[0];
-                    }
+                if (conv_fuses_stats(o, ti)) {
+                    const int hwg = o.cd.transposed ? ti.H * ti.W : oh * conv_out_dim(o.cd, ti.W, o.cd.kw);
+                    const size_t tiles = (size_t)o.phases.size() * N * (hwg / 128);
+                    st.fused_stats = true; st.tiles_per_image = hwg / 128;
+                    slab_bytes[i] = tiles * 2 * o.cd.cout * sizeof(float);
+                    st.aux_off[0] = arena.alloc(slab_bytes[i]);
+                    slab_off[i] = st.aux_off[0];
                 }
                 break;
             }
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
-                rc = set_out(ti.H, ti.W);
-                st.aux_off[1] = arena.alloc((size_t)N * ti.C * 2 * sizeof(float));
+                const size_t mr_bytes = (size_t)N * ti.C * 2 * sizeof(float);
+                if (st.norm_into < 0) alloc_out();
+                st.aux_off[1] = arena.alloc(mr_bytes);
                 if (o.stats_from >= 0 && slab_bytes[o.stats_from]) {
                     st.fused_stats = true;
                     st.tiles_per_image = plan.steps[o.stats_from].tiles_per_image;
@@ -204,14 +280,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                     st.aux_off[0] = arena.alloc((size_t)N * chunks * 2 * ti.C * sizeof(float));
                     arena.release(st.aux_off[0], (size_t)N * chunks * 2 * ti.C * sizeof(float));
                 }
-                arena.release(st.aux_off[1], (size_t)N * ti.C * 2 * sizeof(float));
+                if (st.norm_into >= 0) deferred[st.norm_into].push_back({st.aux_off[1], mr_bytes});   // the conv reads it
+                else arena.release(st.aux_off[1], mr_bytes);
                 break;
             }
-            case OP_MAXPOOL: {
-                const Tensor& ti = T[o.in];
-                rc = set_out((ti.H + 2 * o.p - o.k) / o.s + 1, (ti.W + 2 * o.p - o.k) / o.s + 1);
-                break;
-            }
+            case OP_MAXPOOL: alloc_out(); break;
             case OP_GEM: {
                 const Tensor& ti = T[o.in];
                 st.aux_off[0] = arena.alloc((size_t)N * ti.C * sizeof(float));
@@ -230,15 +303,14 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 break;
             }
         }
-        if (rc != GDT_OK) return rc;
         // free dead inputs
         auto maybe_free = [&](int t) {
-            if (t >= 0 && T[t].last_use == (int)i && T[t].bytes) { arena.release(T[t].off, T[t].bytes); T[t].last_use = -2; }
+            if (t >= 0 && T[t].last_use == i && T[t].bytes) { arena.release(T[t].off, T[t].bytes); T[t].last_use = -2; }
         };
-        maybe_free(o.in); maybe_free(o.res);
+        maybe_free(o.kind == OP_CONV ? conv_input(i) : o.in); maybe_free(o.res);
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) maybe_free(o.feats[k]);
-        if (o.out >= 0 && T[o.out].last_use == -1) { arena.release(T[o.out].off, T[o.out].bytes); }   // never consumed
-        plan.steps.push_back(st);
+        if (o.out >= 0 && T[o.out].last_use == -1 && T[o.out].bytes) arena.release(T[o.out].off, T[o.out].bytes);   // never consumed
+        for (auto& r : deferred[i]) arena.release(r.first, r.second);
     }
     plan.peak = arena.peak;
     return GDT_OK;
@@ -626,30 +698,24 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 const Tensor& ti = T[o.in];
                 ConvLaunch d{};
                 d.in = tptr(o.in);
-                d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
+                if (stp.norm_from >= 0) {      // InstanceNorm(+ReLU) of the producer applied while staging the input
+                    const Op& nj = net->ops[stp.norm_from];
+                    d.in = tptr(nj.in);
+                    d.in_norm = (const float*)(ws + plan.steps[stp.norm_from].aux_off[1]);
+                    d.in_relu = nj.relu;
+                }
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
-                d.N = n; d.H = ti.H; d.W = ti.W; d.Cin = o.cin_pad; d.lc8 = ilog2(o.cin_pad / 8);
-                d.Cout = o.cd.cout; d.CoutPad = o.cout_pad;
-                d.OH = conv_out_dim(o.cd, ti.H, o.cd.kh); d.OW = conv_out_dim(o.cd, ti.W, o.cd.kw);
-                if (o.rowsplit) { d.out = (f16*)(ws + stp.aux_off[1]); d.out_f32 = nullptr; d.Cout = o.rs_cout8; d.OW = ti.W; d.bias = nullptr; }
-                else if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
-                else { d.out = tptr(o.out); d.out_f32 = nullptr; }
-                d.pad_reflect = o.cd.pad_reflect; d.relu = o.cd.relu; d.act = o.cd.act;
                 d.stats = stp.fused_stats ? (float*)(ws + stp.aux_off[0]) : nullptr;
                 int phase_idx = 0;
                 for (const PackedPhase& ph : o.phases) {
+                    conv_geometry(net, o, ph, n, ti, d);
+                    d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
+                    if (o.rowsplit) { d.out = (f16*)(ws + stp.aux_off[1]); d.out_f32 = nullptr; d.Cout = o.rs_cout8; d.bias = nullptr; }
+                    else if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
+                    else { d.out = tptr(o.out); d.out_f32 = nullptr; }
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
                     d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
-                    d.Kpad = ph.Kpad; d.nk = ph.Kpad / (f32 ? 32 : 64);
-                    d.ntaps = ph.ntaps; d.TW = ph.TW; d.invTW = (65536 + ph.TW - 1) / ph.TW;
-                    d.dy0 = ph.dy0; d.dys = ph.dys; d.dx0 = ph.dx0; d.dxs = ph.dxs;
-                    if (o.cd.transposed) {
-                        d.OHg = ti.H; d.OWg = ti.W; d.sy = d.sx = 1; d.osy = d.osx = 2; d.ooy = ph.ooy; d.oox = ph.oox;
-                    } else {
-                        d.OHg = d.OH; d.OWg = d.OW; d.sy = d.sx = o.cd.stride; d.osy = d.osx = 1; d.ooy = d.oox = 0;
-                    }
-                    d.M = n * d.OHg * d.OWg;
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
@@ -665,7 +731,11 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
             }
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
-                if (stp.fused_stats)
+                if (stp.norm_into >= 0)     // the consuming conv applies it: only mean / rstd are produced here
+                    rc = gdt_k_instance_norm_stats(tptr(o.in), f32, stp.fused_stats, (float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
+                                                   stp.fused_stats ? (int)net->ops[o.stats_from].phases.size() : 1,
+                                                   (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, st);
+                else if (stp.fused_stats)
                     rc = gdt_k_instance_norm_fused(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), f32,
                                                    (const float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
                                                    (int)net->ops[o.stats_from].phases.size(), (float*)(ws + stp.aux_off[1]), n,
