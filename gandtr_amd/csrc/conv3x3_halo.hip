@@ -213,11 +213,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
-                    if (more && i * TN + j == ((TM * TN) / 2 > 0 ? (TM * TN) / 2 - 1 : 0)) {
-                        if (BR == 4) issue_b(nkoff, (s + 1) & 1, kk);
-                        else if (BR == 2) { if (kk < 2) issue_b(nkoff, (s + 1) & 1, kk); }
-                        else { if (kk == 0) issue_b(nkoff, (s + 1) & 1, 0); }
-                    }
+                    // next step's weight tile: all rounds early in the step (every second MFMA of the first k-substep), so
+                    // the DMA has most of the step to land before the barrier that publishes it
+                    if (more && kk == 0 && (i * TN + j) % 2 == 1 && (i * TN + j) / 2 < BR) issue_b(nkoff, (s + 1) & 1, (i * TN + j) / 2);
+                    if (more && kk == 0 && TM * TN == 1 && BR == 1) issue_b(nkoff, (s + 1) & 1, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -225,6 +224,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
     }
 
     // ---------------------------------------------------------------- epilogue (fp16 NHWC through an LDS transpose)
+    if (d.dbg & 4) return;            // timing-only ablation
     constexpr int CP = BN + 8;
     __syncthreads();
     f16* Ct = (f16*)smem;
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         }
     }
     constexpr int CPR = BN / 8, NCH = BM * CPR / NT;
+    if (d.dbg & 8) return;            // timing-only ablation: LDS transpose done, no global stores
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int id = k * NT + tid;
