@@ -2,7 +2,7 @@
 
 metric (BASELINE.json): images/sec generator@256^2 + descriptors/sec GeM-R101@1024^2.
   primary   `value`      : CycleGAN ResnetGenerator (InstanceNorm, 9 blocks) forward, batch 64x3x256x256 per GPU
-  secondary `secondary`  : GeM-ResNet-101 single-scale descriptors on 3x1024x1024, batch 16 per GPU, + all-gather for N>1
+  secondary `secondary`  : GeM-ResNet-101 single-scale descriptors on 3x1024x1024, batch 32 per GPU, + all-gather for N>1
 A "step" is one pass of the hot path over one batch already resident in HBM.  One process per GPU; N>1 is launched by
 torch.distributed.run (RCCL); every rank processes its own batch (weak scaling), the only collective is the descriptor
 all-gather of the secondary workload.
@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gen-batch", type=int, default=64)
-    ap.add_argument("--r101-batch", type=int, default=16)
+    ap.add_argument("--r101-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the f16x3 (1e-3-exact) generator measurement")
     ap.add_argument("--no-secondary", action="store_true")

@@ -1,0 +1,123 @@
+"""Throughput of every BASELINE.json configuration on ONE MI355X (development tool; bench.py is the driver's contract).
+
+  c0  cyclegan forward, 4x3x256x256, hub entrypoint on the CPU (plumbing)             -> images/s
+  c1  gem_vgg16_cyclegan descriptors, batch 32x3x1024x1024, single scale              -> descriptors/s
+  c2  hedngan (BatchNorm) generator + HED edge branch, batch 64x3x256x256             -> images/s
+  c3  gem_resnet101_hedngan multi-scale descriptors + lw whitening, 3x1024x1024       -> descriptors/s
+      (scales hub default {1, 1/sqrt2, 1/2} and 'sms' {1, 1/sqrt2, sqrt2}; one rank's share of the 8-GPU job)
+  c4  augment-then-embed: cyclegan on 128x3x256x256 -> meanstd_post -> GeM-ResNet101  -> images/s
+Everything runs through the hub / wrapper / network-container API of the host mirror (the drop-in surface).
+"""
+import json
+import math
+import os
+import pickle
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import hubconf                                         # noqa: E402
+from gandtr_amd.learning import network as N          # noqa: E402
+from gandtr_amd.learning.checkpoints import Checkpoints  # noqa: E402
+from gandtr_amd.tools import synth                    # noqa: E402
+
+
+def rate(fn, units, steps=8, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return round(units / dt, 1), round(dt * 1e3, 2)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    out = {}
+    with torch.no_grad():
+        # c0 (CPU plumbing)
+        net = hubconf.cyclegan(pretrained=False, device="cpu")
+        x = synth.synth_input(1, (4, 3, 256, 256), 1.0)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        net(x)
+        t0 = time.perf_counter(); net(x); dt = time.perf_counter() - t0
+        out["c0_cyclegan_cpu_4x256"] = {"images_per_s": round(4 / dt, 2), "threads": torch.get_num_threads()}
+
+        # c1
+        net = hubconf.gem_vgg16_cyclegan(pretrained=False, device=dev)
+        net.model.load_state_dict(synth.vgg16_state(0))
+        x = synth.synth_input(2, (32, 3, 1024, 1024)).to(dev)
+        r, ms = rate(lambda: net(x), 32, steps=4, warmup=1)
+        out["c1_gem_vgg16_32x1024"] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * 641.4 / 1e3, 1)}
+        del net, x
+        torch.cuda.empty_cache()
+
+        # c2: hedngan generator (BN) + HED branch with its wrappers (edges_epochs.py:87, forward only)
+        gen = hubconf.hedngan(pretrained=False, device=dev)
+        gen.model.load_state_dict(synth.generator_state(0, "batch"))
+        hed = N.initialize_network({"type": "SingleNetwork", "model": {"architecture": "hed_interpolation"}, "initialize": False,
+                                    "runtime": {"wrappers": "rgb2bgr_pre, meanstd_pre:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:"
+                                                            "[[0.40787054,0.45752458,0.48109378],[1,1,1]]"}}, dev).eval()
+        hed.model.load_state_dict(synth.hed_state(0))
+        x = synth.synth_input(3, (64, 3, 256, 256), 1.0).to(dev)
+        r, ms = rate(lambda: hed(gen(x)), 64)
+        rg, msg = rate(lambda: gen(x), 64)
+        out["c2_hedngan_plus_hed_64x256"] = {"images_per_s": r, "ms_per_batch": ms, "generator_only_images_per_s": rg,
+                                             "tflops": round(r * 139.2 / 1e3, 1)}
+        del gen, hed, x
+        torch.cuda.empty_cache()
+
+        # c3: pretrained-style path (checkpoint + lw.pkl -> whiten + multiscale wrappers), batch of 8 per call
+        tmp = tempfile.mkdtemp()
+        base = hubconf.gem_resnet101_hedngan(pretrained=False, device="cpu")
+        base.model.load_state_dict(synth.resnet101_state(0))
+        sd = base.state_dict()["net"]
+        sd["network_params"]["runtime"]["data"] = {"transforms": "pil2np | totensor | normalize",
+                                                   "mean_std": [[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]]}
+        torch.save(sd, os.path.join(tmp, "r101.pth"))
+        with open(os.path.join(tmp, "lw.pkl"), "wb") as f:
+            pickle.dump(synth.whitening_state(0, 2048), f)
+        x = synth.synth_input(4, (8, 3, 1024, 1024)).to(dev)
+        for tag, scales in (("hub_default", True), ("sms", "sms")):
+            runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": os.path.join(tmp, "lw.pkl"), "dimensions": None},
+                                                            "1_cirmultiscale": {"scales": scales}}}}
+            net = N.initialize_network(None, dev, Checkpoints.load_network(os.path.join(tmp, "r101.pth")), runtime).eval()
+            r, ms = rate(lambda: net(x), 8, steps=4, warmup=1)
+            gf = 574.8 if scales is True else 1151.9
+            out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1)}
+            del net
+        del x
+        torch.cuda.empty_cache()
+
+        # c4: augment -> embed chain through CirSequentialNetwork
+        gen_p = {"type": "SingleNetwork",
+                 "model": {"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "n_blocks": 9,
+                           "norm_layer": "instance", "no_antialias": True, "no_antialias_up": True},
+                 "initialize": False,
+                 "runtime": {"wrappers": "meanstd_post:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.485,0.456,0.406],[0.229,0.224,0.225]]",
+                             "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+        emb_p = {"type": "SingleNetwork",
+                 "model": {"architecture": "cirnet", "cir_architecture": "resnet101", "local_whitening": False, "pooling": "gem",
+                           "pretrained": False, "regional": False, "whitening": False},
+                 "initialize": False,
+                 "runtime": {"wrappers": "cirfaketuplebatch",
+                             "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+        chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_p, "embed": emb_p},
+                                     dev).eval()
+        chain.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance"))
+        chain.networks["embed"].model.load_state_dict(synth.resnet101_state(0))
+        x = synth.synth_input(5, (128, 3, 256, 256), 1.0).to(dev)
+        r, ms = rate(lambda: chain(x), 128)
+        out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
