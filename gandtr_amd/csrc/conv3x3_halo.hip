@@ -64,15 +64,18 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
     const int y0 = (tr / tiles_x) << 4, x0 = (tr % tiles_x) << 4;
 
     // ---- loader state
+    // LDS swizzle of the halo image: chunk' = chunk ^ ((halo column >> 1) & 7).  With 18-pixel halo rows this keeps every
+    // 16-lane ds_read_b128 group of a fragment read (two patch rows, 16 + 16 pixels) on 16 distinct 16-byte slots for all
+    // nine taps (the generic (row >> 1) & 7 swizzle is 2-way conflicted here: SQ_LDS_BANK_CONFLICT was 38 % of LDS cycles).
     const int lrow = tid >> 3;                          // 0..63
-    const int swz = (lrow >> 1) & 7;
-    const int q = (lane & 7) ^ swz;
+    const int q = (lane & 7) ^ ((lrow >> 1) & 7);       // weight tile: generic swizzle
     const bool refl = d.pad_reflect != 0;
-    int a_pix[6]; unsigned a_ok = 0;
+    int a_pix[6], a_q[6]; unsigned a_ok = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int h = r * 64 + lrow;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
+        a_q[r] = (lane & 7) ^ ((hx >> 1) & 7);
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
         int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
@@ -85,16 +88,16 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
 
     auto issue_a = [&](int chunk, int stage, int r) {
         if (r * 64 + wave * 8 >= HALO_ROWS_PAD) return;            // wave-uniform: rows beyond the padded halo
-        const f16* src = d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + q) * 8);
+        const f16* src = d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8);
         glds16(((a_ok >> r) & 1u) ? src : d.zeros, smem + stage * A_BYTES + (r * 64 + wave * 8) * ROWB);
     };
     // Fused InstanceNorm (+ReLU) of the producer (p2p_networks.py:29,:272): when d.in_norm is set the halo goes through
     // registers instead -- load 8 raw fp16 channels, x -> max((x - mean) * rstd, 0) in fp32, store to the same swizzled LDS
     // slot the DMA path would have filled.  One piece per tap step, written one step after it was issued.
     const bool norm_a = d.in_norm != nullptr;     // wave-uniform
-    float nmr[16];                                // (mean, rstd) of this lane's 8 channels in the chunk being staged
-    auto load_norm = [&](int chunk) {
-        const float4* p = (const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64 + q * 8) * 2);
+    float nmr[16];                                // (mean, rstd) of the 8 channels of the piece in flight
+    auto load_norm = [&](int chunk, int r) {
+        const float4* p = (const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64 + a_q[r] * 8) * 2);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const float4 v = p[k]; nmr[4 * k] = v.x; nmr[4 * k + 1] = v.y; nmr[4 * k + 2] = v.z; nmr[4 * k + 3] = v.w; }
     };
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
         if (r * 64 + lrow < HALO_ROWS_PAD && ((a_ok >> r) & 1u))
-            v = *(const f16x8*)(d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + q) * 8));
+            v = *(const f16x8*)(d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8));
         return v;
     };
     auto store_piece = [&](int stage, int r, const f16x8& raw) {
@@ -132,24 +135,25 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    int a_h0[TM], b_off[TN], b_sw[TN];
+    // fragment addresses: row base | ((first chunk ^ swizzle) << 4); the k-substep kk is applied with ONE xor (kk << 5),
+    // because (2*kk + fh) ^ sw == (2*kk) ^ (fh ^ sw) and the row bases are multiples of 128
+    int a_h0[TM], a_px[TM], b_base[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wm * WTM + i * 32 + fr;
-        a_h0[i] = (m >> 4) * HALO_W + (m & 15);
+        a_h0[i] = (m >> 4) * HALO_W + (m & 15); a_px[i] = m & 15;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + fr;
-        b_off[j] = row * ROWB; b_sw[j] = (row >> 1) & 7;
+        b_base[j] = 2 * A_BYTES + row * ROWB + ((fh ^ ((row >> 1) & 7)) << 4);
     }
 
     const int nchunks = d.Cin >> 6;
     const int total = nchunks * 9;
     if (norm_a) {
-        load_norm(0);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) store_piece(0, r, load_piece(0, r));
+        for (int r = 0; r < 6; ++r) { load_norm(0, r); store_piece(0, r, load_piece(0, r)); }
     } else {
 #pragma unroll
         for (int r = 0; r < 6; ++r) issue_a(0, 0, r);
@@ -170,24 +174,20 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
         const bool halo_more = (c + 1 < nchunks) && t < 6 && !norm_a;
         if (norm_a && c + 1 < nchunks) {
-            // nmr holds chunk c+1's statistics from tap 0 on: every piece of chunk c+1 is normalised with them
-            if (t >= 1 && t <= 6) store_piece((c + 1) & 1, t - 1, pend);
-            if (t == 0) load_norm(c + 1);
-            if (t < 6) pend = load_piece(c + 1, t);
+            if (t >= 1 && t <= 6) store_piece((c + 1) & 1, t - 1, pend);      // uses the statistics loaded with that piece
+            if (t < 6) { load_norm(c + 1, t); pend = load_piece(c + 1, t); }
         }
-        const char* As = smem + (c & 1) * A_BYTES;
-        const char* Bs = smem + 2 * A_BYTES + (s & 1) * B_BYTES;
         const int ty = (t * 21846) >> 16, tx = t - ty * 3;
-        int a_off[TM], a_sw[TM];
+        int a_ad[TM], b_ad[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int h = a_h0[i] + ty * HALO_W + tx;
-            a_off[i] = h * ROWB; a_sw[i] = (h >> 1) & 7;
-        }
+        for (int i = 0; i < TM; ++i)
+            a_ad[i] = (c & 1) * A_BYTES + (a_h0[i] + ty * HALO_W + tx) * ROWB + ((fh ^ (((a_px[i] + tx) >> 1) & 7)) << 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) afr[0][i] = *(const f16x8*)(As + a_off[i] + ((fh ^ a_sw[i]) << 4));
+        for (int j = 0; j < TN; ++j) b_ad[j] = b_base[j] + (s & 1) * B_BYTES;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[0][j] = *(const f16x8*)(Bs + b_off[j] + ((fh ^ b_sw[j]) << 4));
+        for (int i = 0; i < TM; ++i) afr[0][i] = *(const f16x8*)(smem + a_ad[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[0][j] = *(const f16x8*)(smem + b_ad[j]);
         if (d.dbg & 2) {       // timing-only ablation: staging without MFMAs
             if (halo_more) issue_a(c + 1, (c + 1) & 1, t);
             if (more) {
@@ -201,11 +201,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
             if (kk + 1 < 4) {
-                const int ch = 2 * (kk + 1) + fh;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) afr[nxt][i] = *(const f16x8*)(As + a_off[i] + ((ch ^ a_sw[i]) << 4));
+                for (int i = 0; i < TM; ++i) afr[nxt][i] = *(const f16x8*)(smem + (a_ad[i] ^ ((kk + 1) << 5)));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
+                for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(smem + (b_ad[j] ^ ((kk + 1) << 5)));
             }
             if (kk == 1 && halo_more) issue_a(c + 1, (c + 1) & 1, t);
 #pragma unroll

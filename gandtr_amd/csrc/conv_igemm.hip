@@ -339,7 +339,8 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     const long tiles256 = ((long)d.M + 255) / 256;
     static const int force_tile = [] { const char* e = getenv("GDT_CONV_TILE"); return e ? atoi(e) : 0; }();   // test knob
     const long min_blocks = force_tile == 256 ? 1 : 512;
-    if (force_tile != 128 && !d.in_norm) {
+    static const int min_nk = [] { const char* e = getenv("GDT_CONV_MINK"); return e ? atoi(e) : 0; }();
+    if (force_tile != 128 && !d.in_norm && (d.nk >= min_nk || force_tile == 256)) {
         if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
         if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
     }
