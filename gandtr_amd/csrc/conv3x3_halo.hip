@@ -21,36 +21,43 @@
 namespace {
 
 constexpr int ROWB = 128;          // bytes per LDS row (64 halves of K)
-constexpr int HALO_W = 18, HALO_ROWS = 324, HALO_ROWS_PAD = 328;
-constexpr int A_BYTES = HALO_ROWS_PAD * ROWB;
-constexpr int NT = 512;
+constexpr int HALO_W = 18;
+// patch height PH (16 or 8 output rows x 16 columns): halo (PH+2) x 18 rows of 128 B, padded to a multiple of 8 rows
+constexpr int halo_rows(int PH) { return (PH + 2) * HALO_W; }
+constexpr int halo_rows_pad(int PH) { return (halo_rows(PH) + 7) / 8 * 8; }
+constexpr int a_bytes(int PH) { return halo_rows_pad(PH) * ROWB; }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
 }
 
-template <int BN, int WGM, int WGN>
+template <int PH, int BN, int WGM, int WGN>
 constexpr size_t halo_lds_bytes() {
-    constexpr size_t staging = 2 * (size_t)A_BYTES + 2 * (size_t)BN * ROWB;
-    constexpr size_t epilogue = ((size_t)256 * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+    constexpr size_t staging = 2 * (size_t)a_bytes(PH) + 2 * (size_t)BN * ROWB;
+    constexpr size_t epilogue = ((size_t)PH * 16 * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
     return staging > epilogue ? staging : epilogue;
 }
 
-template <int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
-    static_assert(WGM * WGN == 8, "8 wavefronts");
-    constexpr int BM = 256;
+// PH = 16, 8 wavefronts: one 256 x BN tile per CU.  PH = 8, 4 wavefronts, BN = 128: 78 KB of LDS, so TWO workgroups share a
+// CU and fill each other's barrier / first-fragment bubbles (the single-workgroup form spends ~30 % of its wave cycles there).
+template <int PH, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const ConvLaunch d) {
+    constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, tile rows staged per loader round
+    constexpr int BM = PH * 16;
+    constexpr int HALO_ROWS = halo_rows(PH), HALO_ROWS_PAD = halo_rows_pad(PH), A_BYTES = a_bytes(PH);
+    constexpr int NR = (HALO_ROWS_PAD + RPR - 1) / RPR;         // halo staging rounds per chunk
+    static_assert(NR <= 6, "halo rounds are spread over taps 0..5");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int BR = BN / 64;                        // weight staging rounds per step (64 rows per round)
-    static_assert(BR >= 1 && TM >= 1 && TN >= 1, "tile shape");
+    constexpr int BR = BN / RPR;                       // weight staging rounds per step
+    static_assert(BR >= 1 && TM >= 1 && TN >= 1 && BN % RPR == 0, "tile shape");
     constexpr int B_BYTES = BN * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + 15) >> 4;
+    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + PH - 1) / PH;
     const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
     int tile_m, tile_n;
     {
@@ -61,19 +68,19 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         if (tile_m >= ntm) return;
     }
     const int n = tile_m / tpi, tr = tile_m - n * tpi;
-    const int y0 = (tr / tiles_x) << 4, x0 = (tr % tiles_x) << 4;
+    const int y0 = (tr / tiles_x) * PH, x0 = (tr % tiles_x) << 4;
 
     // ---- loader state
     // LDS swizzle of the halo image: chunk' = chunk ^ ((halo column >> 1) & 7).  With 18-pixel halo rows this keeps every
     // 16-lane ds_read_b128 group of a fragment read (two patch rows, 16 + 16 pixels) on 16 distinct 16-byte slots for all
     // nine taps (the generic (row >> 1) & 7 swizzle is 2-way conflicted here: SQ_LDS_BANK_CONFLICT was 38 % of LDS cycles).
-    const int lrow = tid >> 3;                          // 0..63
+    const int lrow = tid >> 3;                          // 0..RPR-1
     const int q = (lane & 7) ^ ((lrow >> 1) & 7);       // weight tile: generic swizzle
     const bool refl = d.pad_reflect != 0;
-    int a_pix[6], a_q[6]; unsigned a_ok = 0;
+    int a_pix[NR], a_q[NR]; unsigned a_ok = 0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int h = r * 64 + lrow;
+    for (int r = 0; r < NR; ++r) {
+        const int h = r * RPR + lrow;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
         a_q[r] = (lane & 7) ^ ((hx >> 1) & 7);
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -87,9 +94,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
     const f16* b_src = d.w + ((long)(tile_n * BN + lrow) * d.Kpad + q * 8);
 
     auto issue_a = [&](int chunk, int stage, int r) {
-        if (r * 64 + wave * 8 >= HALO_ROWS_PAD) return;            // wave-uniform: rows beyond the padded halo
+        if (r >= NR || r * RPR + wave * 8 >= HALO_ROWS_PAD) return;  // wave-uniform: rows beyond the padded halo
         const f16* src = d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8);
-        glds16(((a_ok >> r) & 1u) ? src : d.zeros, smem + stage * A_BYTES + (r * 64 + wave * 8) * ROWB);
+        glds16(((a_ok >> r) & 1u) ? src : d.zeros, smem + stage * A_BYTES + (r * RPR + wave * 8) * ROWB);
     };
     // Fused InstanceNorm (+ReLU) of the producer (p2p_networks.py:29,:272): when d.in_norm is set the halo goes through
     // registers instead -- load 8 raw fp16 channels, x -> max((x - mean) * rstd, 0) in fp32, store to the same swizzled LDS
@@ -105,13 +112,13 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
-        if (r * 64 + lrow < HALO_ROWS_PAD && ((a_ok >> r) & 1u))
+        if (r < NR && r * RPR + lrow < HALO_ROWS_PAD && ((a_ok >> r) & 1u))
             v = *(const f16x8*)(d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8));
         return v;
     };
     auto store_piece = [&](int stage, int r, const f16x8& raw) {
-        const int row = r * 64 + lrow;
-        if (row >= HALO_ROWS_PAD) return;
+        const int row = r * RPR + lrow;
+        if (r >= NR || row >= HALO_ROWS_PAD) return;
         f16x8 o;
         const bool ok = (a_ok >> r) & 1u;                      // padded positions stay exactly zero
 #pragma unroll
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         *(f16x8*)(smem + stage * A_BYTES + row * ROWB + ((lane & 7) << 4)) = o;
     };
     auto issue_b = [&](int koff, int stage, int r) {
-        glds16(b_src + ((long)r * 64 * d.Kpad + koff), smem + 2 * A_BYTES + stage * B_BYTES + (r * 64 + wave * 8) * ROWB);
+        glds16(b_src + ((long)r * RPR * d.Kpad + koff), smem + 2 * A_BYTES + stage * B_BYTES + (r * RPR + wave * 8) * ROWB);
     };
 
     f32x16 acc[TM][TN];
@@ -153,10 +160,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
     const int total = nchunks * 9;
     if (norm_a) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { load_norm(0, r); store_piece(0, r, load_piece(0, r)); }
+        for (int r = 0; r < NR; ++r) { load_norm(0, r); store_piece(0, r, load_piece(0, r)); }
     } else {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) issue_a(0, 0, r);
+        for (int r = 0; r < NR; ++r) issue_a(0, 0, r);
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
@@ -172,10 +179,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         int nc = c, nt = t + 1;
         if (nt == 9) { nt = 0; nc = c + 1; }
         const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
-        const bool halo_more = (c + 1 < nchunks) && t < 6 && !norm_a;
+        const bool halo_more = (c + 1 < nchunks) && t < NR && !norm_a;
         if (norm_a && c + 1 < nchunks) {
-            if (t >= 1 && t <= 6) store_piece((c + 1) & 1, t - 1, pend);      // uses the statistics loaded with that piece
-            if (t < 6) { load_norm(c + 1, t); pend = load_piece(c + 1, t); }
+            if (t >= 1 && t <= NR) store_piece((c + 1) & 1, t - 1, pend);     // uses the statistics loaded with that piece
+            if (t < NR) { load_norm(c + 1, t); pend = load_piece(c + 1, t); }
         }
         const int ty = (t * 21846) >> 16, tx = t - ty * 3;
         int a_ad[TM], b_ad[TN];
@@ -212,10 +219,14 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
-                    // next step's weight tile: all rounds early in the step (every second MFMA of the first k-substep), so
-                    // the DMA has most of the step to land before the barrier that publishes it
-                    if (more && kk == 0 && (i * TN + j) % 2 == 1 && (i * TN + j) / 2 < BR) issue_b(nkoff, (s + 1) & 1, (i * TN + j) / 2);
-                    if (more && kk == 0 && TM * TN == 1 && BR == 1) issue_b(nkoff, (s + 1) & 1, 0);
+                    // next step's weight tile: one staging round after every second MFMA from the start of the step, so the
+                    // DMA has most of the step to land before the barrier that publishes it
+                    {
+                        constexpr int PER_KK = (TM * TN + 1) / 2;                 // issue slots per k-substep
+                        const int slot = kk * PER_KK + (i * TN + j) / 2;
+                        const bool at_slot = (TM * TN == 1) ? true : ((i * TN + j) % 2 == 1);
+                        if (more && at_slot && slot < BR) issue_b(nkoff, (s + 1) & 1, slot);
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -251,16 +262,16 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
         }
     }
     __syncthreads();
-    constexpr int WPR = WGM / 2;            // wave rows per 128-row statistics record (2 records per tile)
-    static_assert(WGM % 2 == 0 && BN * 2 <= NT, "statistics record layout");
-    if (d.stats && tid < BN * 2) {
+    constexpr int RT = BM / 128, WPR = WGM / RT;     // 128-row statistics records per tile, wave rows per record
+    static_assert(WGM % RT == 0 && BN * RT <= NT, "statistics record layout");
+    if (d.stats && tid < BN * RT) {
         const int rec = tid / BN, col = tid % BN;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
         const int gcol = tile_n * BN + col;
         if (gcol < d.Cout) {
-            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * 2 + rec) * 2) * d.Cout + gcol;
+            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
             dst[0] = s1; dst[d.Cout] = s2;
         }
     }
@@ -288,19 +299,19 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const ConvLaunch d) {
     }
 }
 
-template <int BN, int WGM, int WGN>
+template <int PH, int BN, int WGM, int WGN>
 int launch_halo(const ConvLaunch& d, hipStream_t stream) {
-    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16), ntn = d.CoutPad / BN;
+    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
     const int ntm8 = (tiles + 7) / 8 * 8;
-    constexpr size_t lds = halo_lds_bytes<BN, WGM, WGN>();
+    constexpr size_t lds = halo_lds_bytes<PH, BN, WGM, WGN>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WGM, WGN>,
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<PH, BN, WGM, WGN>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(NT), lds, stream, d);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PH, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -316,7 +327,7 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d) {
                        d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Cin % 64 == 0 && !d.out_f32 && d.Cout % 8 == 0 &&
                        d.OH == d.H && d.OW == d.W && d.Kpad == 9 * d.Cin && d.CoutPad % 64 == 0;
     if (!shape) return false;
-    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
+    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;     // whole patches: the 128-row statistics records line up
     if (mode == 2) return true;
     const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
@@ -329,7 +340,9 @@ int gdt_launch_conv_halo(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
-    if (d.CoutPad % 256 == 0) return launch_halo<256, 2, 4>(d, stream);
-    if (d.CoutPad % 128 == 0) return launch_halo<128, 4, 2>(d, stream);
-    return launch_halo<64, 8, 1>(d, stream);
+    static const int small = [] { const char* e = getenv("GDT_HALO_SMALL"); return e ? atoi(e) : 0; }();   // experiment knob
+    if (small && d.CoutPad % 128 == 0) return launch_halo<8, 128, 2, 2>(d, stream);      // two workgroups per CU
+    if (d.CoutPad % 256 == 0) return launch_halo<16, 256, 2, 4>(d, stream);
+    if (d.CoutPad % 128 == 0) return launch_halo<16, 128, 4, 2>(d, stream);
+    return launch_halo<16, 64, 8, 1>(d, stream);
 }
