@@ -141,7 +141,8 @@ struct Plan { std::vector<Step> steps; size_t peak = 0; };
 
 int conv_out_dim(const gdt_conv_desc& c, int in, int k) {
     if (c.transposed) return in * 2;
-    return (in + 2 * c.pad - k) / c.stride + 1;
+    const int span = in + 2 * c.pad - k;
+    return span < 0 ? 0 : span / c.stride + 1;          // floor semantics; 0 = empty (rejected by the planner)
 }
 
 // geometry part of a conv launch (everything but the pointers) for one phase of op `o` reading a tensor of size ti
@@ -191,7 +192,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 break;
             }
             case OP_INORM: h = T[o.in].H; w = T[o.in].W; break;
-            case OP_MAXPOOL: h = (T[o.in].H + 2 * o.p - o.k) / o.s + 1; w = (T[o.in].W + 2 * o.p - o.k) / o.s + 1; break;
+            case OP_MAXPOOL:
+                h = T[o.in].H + 2 * o.p - o.k < 0 ? 0 : (T[o.in].H + 2 * o.p - o.k) / o.s + 1;
+                w = T[o.in].W + 2 * o.p - o.k < 0 ? 0 : (T[o.in].W + 2 * o.p - o.k) / o.s + 1;
+                break;
             default: break;
         }
         if (o.out >= 0) {

@@ -164,3 +164,47 @@ def test_embedder_f16x3(cuda_device, arch):
     net = build_embedder(sd, cuda_device, precision="f16x3")
     got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
     assert float((got - ref).abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------- ragged / edge geometries
+@pytest.mark.parametrize("shape", [(1, 3, 100, 76), (3, 3, 36, 132), (1, 3, 20, 20)])
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_ragged_sizes(cuda_device, norm, shape):
+    """sizes that are not multiples of the 16x16 patch / 128-row tiles (and not of 4: the two stride-2 layers floor, the two
+    transposed convs double -- output size follows the reference), batch 1 and odd batches"""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, ngf=16, n_blocks=3)
+    x = synth.synth_input(11, shape, 1.0)
+    ref = O.resnet_generator(x, sd, norm, 3, pre_tanh=True)
+    for prec, tol in (("f16", 5e-3), ("f16x3", 1e-4)):
+        net = build_generator(sd, cuda_device, pre_tanh=True, precision=prec)
+        got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
+        assert got.shape == ref.shape
+        assert _rel(got, ref) < tol, (prec, _rel(got, ref))
+
+
+@pytest.mark.parametrize("arch", ["vgg16", "resnet101"])
+def test_embedder_ragged_sizes(cuda_device, arch):
+    from gandtr_amd.engine import build_embedder
+    sd = synth.vgg16_state(0) if arch == "vgg16" else synth.resnet101_state(0)
+    net = build_embedder(sd, cuda_device)
+    for shape in ((1, 3, 250, 333), (3, 3, 97, 64)):
+        x = synth.synth_input(12, shape)
+        ref = O.image_retrieval_forward(x, sd, arch).t().contiguous()
+        got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
+        assert float((got - ref).abs().max()) < 1e-3
+        assert float(torch.nn.functional.cosine_similarity(got, ref, dim=1).min()) > 0.9999
+
+
+def test_invalid_inputs_raise(cuda_device):
+    """empty / too-small inputs: the reference raises from torch (reflection pad larger than the input, empty conv output);
+    the HIP path raises ValueError before launching anything"""
+    from gandtr_amd.engine import build_generator, build_embedder
+    gen = build_generator(synth.generator_state(0, "instance", ngf=8, n_blocks=1), cuda_device)
+    with pytest.raises(ValueError):
+        gen.forward(torch.zeros(1, 3, 3, 3, device=cuda_device))          # reflection pad 3 needs > 3 pixels
+    with pytest.raises(ValueError):
+        gen.forward(torch.zeros(1, 4, 32, 32, device=cuda_device))         # wrong channel count
+    emb = build_embedder(synth.vgg16_state(0, width_div=4), cuda_device)
+    with pytest.raises(ValueError):
+        emb.forward(torch.zeros(1, 3, 8, 8, device=cuda_device))           # four max-pools leave nothing
