@@ -209,3 +209,39 @@ def test_generator_taps_cpu():
     close(out, g["out"])
     for f, i in zip(feats, [1, 2, 3, 10, 19]):
         close(f, g["tap%d" % i])
+
+
+def test_mdir_alias_is_a_drop_in_import():
+    import mdir                                              # noqa: F401
+    from mdir.hub.model import cyclegan as c2
+    from mdir.components.model.network import MODEL_LABELS
+    from mdir.components.data.wrapper import WRAPPERS_LABELS
+    from mdir.learning.network import NETWORKS, initialize_network
+    from mdir.learning import load_network
+    import mdir.stages.infer as stage
+    assert c2 is hubconf.cyclegan and "cirnet" in MODEL_LABELS and "cirwhiten" in WRAPPERS_LABELS
+    assert "SingleNetwork" in NETWORKS and callable(initialize_network) and callable(load_network) and callable(stage.infer)
+
+
+def test_infer_stage_contract(tmp_path):
+    """stage ABI: fn(params, data) -> (metadata, *outputs); embedding and rgb sinks, network given by path or by params"""
+    from gandtr_amd.stages import FUNCTIONS
+    infer = FUNCTIONS["mdir.stages.infer.infer"]
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False, "path": None,
+           "runtime": {"wrappers": "cirfaketuplebatch",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    imgs = [synth.synth_input(20 + i, (3, 64, 80)) for i in range(3)]
+    meta, vecs = infer({"network": emb, "output": {"inference": {"name": "embedding"}}}, (imgs,))
+    assert vecs.shape == (3, 512) and np.allclose(np.linalg.norm(vecs, axis=1), 1.0, atol=1e-4) and meta["stats"]["items"] == 3
+    gen = hubconf.cyclegan(pretrained=False, device="cpu")
+    ck = tmp_path / "gen.pth"
+    sd = gen.state_dict()["net"]
+    sd["network_params"]["runtime"]["data"] = {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}
+    torch.save(sd, ck)
+    meta, pics = infer({"network": {"path": str(ck), "runtime": {"wrappers": ""}}, "output": {"inference": {"name": "rgb"}}},
+                       ([synth.synth_input(30, (3, 32, 32), 1.0)],))
+    assert len(pics) == 1 and pics[0].shape == (32, 32, 3) and 0.0 <= pics[0].min() and pics[0].max() <= 1.0
+    assert infer({"network": emb, "output": {"inference": {"name": "embedding"}}}, ([],)) == ({"status": "skipped"},)
