@@ -9,8 +9,10 @@
 
 PyTorch is used for device memory and streams only; no torch op runs on the data path.
 """
+import collections
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -53,6 +55,11 @@ class HipNet:
         self.in_channels = None
         self._ws = None
         self._finalized = False
+        # hipGraph replay of whole forwards (launch-bound small batches: the reference's own operating point is batch 1)
+        self.use_graphs = os.environ.get("GANDTR_HIP_GRAPHS", "0") == "1"   # measured: no gain (kernels, not launches, bound batch 1)
+        self.graph_max_workspace = 2 << 30      # geometries needing more scratch than this run eagerly
+        self._graphs = collections.OrderedDict()   # key -> dict(graph, x, outs, ws) ; LRU of 8
+        self._seen = {}
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -147,6 +154,7 @@ class HipNet:
         return f.value
 
     def set_profiling(self, enable):
+        self._profiling = bool(enable)          # profiled forwards run eagerly (events are recorded per op)
         _hip.check(self.lib.gdt_net_set_profiling(self.handle, int(enable)))
 
     def profile(self):
@@ -163,9 +171,18 @@ class HipNet:
         _hip.check(self.lib.gdt_net_workspace_bytes(self.handle, n, rh, rw, ctypes.byref(b)))
         return b.value
 
+    def _launch(self, x, n, h, w, rh, rw, rscale, ws, outs):
+        optrs = (ctypes.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _hip.check(self.lib.gdt_net_forward(self.handle, x.data_ptr(), n, h, w, rh, rw, rscale, optrs, len(outs),
+                                            ws.data_ptr(), ws.numel(), stream))
+
     def forward(self, x, scale=None):
         """x: fp32 NCHW tensor on this net's device.  ``scale``: optional F.interpolate scale_factor applied to the
-        input inside the pack kernel.  Returns the list of external outputs (torch tensors on the device)."""
+        input inside the pack kernel.  Returns the list of external outputs (torch tensors on the device).
+
+        A geometry seen for the second time is captured into a hipGraph (static input / output / scratch buffers) and
+        replayed from then on: one graph launch instead of ~100 kernel launches, which is what bounds small batches."""
         if not self._finalized:
             raise RuntimeError("HipNet.forward before finalize()")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
@@ -176,18 +193,55 @@ class HipNet:
         n, _, h, w = x.shape
         rh, rw = self.resized_size(h, w, scale)
         rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
+        key = (n, h, w, rh, rw, rscale)
         with torch.cuda.device(x.device):
+            entry = self._graphs.get(key)
+            if entry is not None:
+                self._graphs.move_to_end(key)
+                entry["x"].copy_(x)
+                entry["graph"].replay()
+                return [o.clone() for o in entry["outs"]]
             need = self.workspace_bytes(n, rh, rw)
+            shapes = self.output_shapes(n, rh, rw)
+            profiling = getattr(self, "_profiling", False)
+            if self.use_graphs and not profiling and need <= self.graph_max_workspace and self._seen.get(key, 0) >= 1 \
+                    and not torch.cuda.is_current_stream_capturing():
+                entry = self._capture(x, key, need, shapes)
+                if entry is not None:
+                    return [o.clone() for o in entry["outs"]]
+            self._seen[key] = self._seen.get(key, 0) + 1
+            if len(self._seen) > 256:
+                self._seen.clear()
             if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
                 self._ws = None
                 self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-            outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in self.output_shapes(n, rh, rw)]
-            optrs = (ctypes.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            _hip.check(self.lib.gdt_net_forward(self.handle, x.data_ptr(), n, h, w, rh, rw, rscale, optrs, len(outs),
-                                                self._ws.data_ptr(), self._ws.numel(), stream))
+            outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in shapes]
+            self._launch(x, n, h, w, rh, rw, rscale, self._ws, outs)
         return outs
 
+    def _capture(self, x, key, need, shapes):
+        n, h, w, rh, rw, rscale = key
+        try:
+            sx = x.clone()
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in shapes]
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):           # warm-up outside capture (lazy function attributes etc.)
+                self._launch(sx, n, h, w, rh, rw, rscale, ws, outs)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch(sx, n, h, w, rh, rw, rscale, ws, outs)
+            g.replay()
+        except Exception:               # capture is an optimisation only: fall back to eager launches for this geometry
+            self._seen[key] = -(1 << 30)
+            return None
+        entry = {"graph": g, "x": sx, "outs": outs, "ws": ws}
+        self._graphs[key] = entry
+        while len(self._graphs) > 8:
+            self._graphs.popitem(last=False)
+        return entry
 
 # ======================================================================================================= builders
 

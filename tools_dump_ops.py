@@ -13,7 +13,7 @@ if which == "gen":
 elif which == "genbn":
     net = engine.build_generator(synth.generator_state(0, "batch"), dev, precision=prec); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
 elif which == "r101":
-    net = engine.build_embedder(synth.resnet101_state(0), dev, precision=prec); x = synth.synth_input(1, (16, 3, 1024, 1024)).to(dev)
+    net = engine.build_embedder(synth.resnet101_state(0), dev, precision=prec); x = synth.synth_input(1, (32, 3, 1024, 1024)).to(dev)
 else:
     net = engine.build_embedder(synth.vgg16_state(0), dev, precision=prec); x = synth.synth_input(1, (8, 3, 1024, 1024)).to(dev)
 for _ in range(3): net.forward(x)
