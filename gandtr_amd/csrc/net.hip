@@ -61,7 +61,7 @@ struct Op {
     int feats[5]; size_t score_w_off[5]; float score_b[5], fusion_w[5], fusion_b = 0.f; int sigmoid = 1;
 };
 
-struct Tensor { int C = 0; int H = 0, W = 0; int last_use = -1; size_t off = 0, bytes = 0; };
+struct Tensor { int C = 0; int Creal = 0; int H = 0, W = 0; int last_use = -1; size_t off = 0, bytes = 0; };   // C: padded, Creal: logical
 
 // first-fit allocator with coalescing free list; "top" grows when nothing fits
 struct Arena {
@@ -127,7 +127,7 @@ struct gdt_net {
         else memset(host_blob.data() + off, 0, bytes);
         return off;
     }
-    int new_tensor(int C) { tensors.push_back(Tensor{C}); return (int)tensors.size() - 1; }
+    int new_tensor(int C, int Creal) { tensors.push_back(Tensor{C, Creal}); return (int)tensors.size() - 1; }
 };
 
 namespace {
@@ -377,7 +377,7 @@ int gdt_net_input(gdt_net* net, int channels, const int* perm, const float* scal
         o.scale[c] = (scale && c < channels) ? scale[c] : 1.f;
         o.shift[c] = (shift && c < channels) ? shift[c] : 0.f;
     }
-    o.out = net->new_tensor(8);
+    o.out = net->new_tensor(8, channels);
     net->input_op = (int)net->ops.size();
     net->ops.push_back(o);
     *out_tensor = o.out;
@@ -395,7 +395,8 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
     GDT_REQUIRE(cd.stride == 1 || cd.stride == 2, "stride must be 1 or 2");
     GDT_REQUIRE((bn_gamma && bn_beta && bn_mean && bn_var) || (!bn_gamma && !bn_beta && !bn_mean && !bn_var), "BN vectors");
     const int cin_pad = next_pow2(cd.cin);
-    GDT_REQUIRE(net->tensors[in_tensor].C == cin_pad, "input tensor channel count does not match conv cin");
+    GDT_REQUIRE(net->tensors[in_tensor].C == cin_pad && net->tensors[in_tensor].Creal == cd.cin,
+                "input tensor channel count does not match conv cin");
     if (cd.transposed) GDT_REQUIRE(cd.kh == 3 && cd.kw == 3 && cd.stride == 2 && cd.pad == 1 && !cd.pad_reflect,
                                    "only ConvTranspose2d(k3,s2,p1,op1) is supported");
     if (!cd.out_f32_nchw) GDT_REQUIRE(cd.cout % 8 == 0, "internal conv outputs need cout % 8 == 0");
@@ -488,7 +489,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         net->out_ops.push_back((int)net->ops.size());
         *out_tensor = o.slot;
     } else {
-        o.out = net->new_tensor(cd.cout);
+        o.out = net->new_tensor(cd.cout, cd.cout);
         *out_tensor = o.out;
     }
     net->ops.push_back(std::move(o));
@@ -502,7 +503,7 @@ int gdt_net_instance_norm(gdt_net* net, int in_tensor, float eps, int relu, int 
     GDT_REQUIRE((C & (C - 1)) == 0 && C >= 8 && C <= 2048, "InstanceNorm needs a power-of-two channel count in [8, 2048]");
     if (residual_tensor >= 0) GDT_REQUIRE(net->tensors[residual_tensor].C == C, "residual channels");
     Op o; o.kind = OP_INORM; o.in = in_tensor; o.res = residual_tensor; o.eps = eps; o.relu = relu;
-    o.out = net->new_tensor(C);
+    o.out = net->new_tensor(C, net->tensors[in_tensor].Creal);
     for (size_t k = 0; k < net->ops.size(); ++k)
         if (net->ops[k].kind == OP_CONV && net->ops[k].out == in_tensor && net->ops[k].stats_for < 0) {
             net->ops[k].stats_for = (int)net->ops.size();
@@ -518,7 +519,7 @@ int gdt_net_maxpool(gdt_net* net, int in_tensor, int kernel, int stride, int pad
     GDT_REQUIRE(in_tensor >= 0 && in_tensor < (int)net->tensors.size(), "tensor id");
     GDT_REQUIRE(kernel >= 1 && stride >= 1 && pad >= 0 && pad * 2 <= kernel, "maxpool geometry");
     Op o; o.kind = OP_MAXPOOL; o.in = in_tensor; o.k = kernel; o.s = stride; o.p = pad;
-    o.out = net->new_tensor(net->tensors[in_tensor].C);
+    o.out = net->new_tensor(net->tensors[in_tensor].C, net->tensors[in_tensor].Creal);
     net->ops.push_back(o);
     *out_tensor = o.out;
     return GDT_OK;

@@ -259,7 +259,7 @@ def generator_layout(sd):
     return norm, w0.shape[0], n_blocks, w0.shape[1], sd["model.%d.weight" % last].shape[0]
 
 
-def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precision="f16"):
+def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precision="f16", finalize=True):
     """ResnetGenerator as a HIP graph.  External outputs: [generator output] + one per requested tap (in ``taps``
     order).  Taps follow the reference's nn.Sequential indices (p2p_networks.py:316-334); a norm-layer tap aliases the
     post-ReLU tensor because the reference's ReLUs are in-place (:272).  Tap 0 / the second reflection pad are not
@@ -313,7 +313,8 @@ def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precisi
     out = net.conv(h, sd[head + ".weight"], sd[head + ".bias"], pad=3, reflect=True, out_f32=True, act=0 if pre_tanh else 1)
     if (i + 2) in taps:
         tap_slots[i + 2] = out
-    net.finalize()
+    if finalize:
+        net.finalize()
     net.out_slot = out
     net.tap_slots = tap_slots
     return net
@@ -362,7 +363,7 @@ def embedder_arch(sd):
     return "resnet" if "features.4.0.conv1.weight" in sd else "vgg16"
 
 
-def build_embedder(sd, device, in_affine=None, feature_tap=False, precision="f16"):
+def build_embedder(sd, device, in_affine=None, feature_tap=False, precision="f16", finalize=True):
     """GeM embedder (ImageRetrievalNet.forward with lwhiten=None, whiten=None).  External output 0: descriptors as a
     row-major [N][D] fp32 matrix (the reference returns its transpose view, D x N)."""
     net = HipNet(device, precision)
@@ -370,14 +371,15 @@ def build_embedder(sd, device, in_affine=None, feature_tap=False, precision="f16
     f = _resnet_trunk(net, x, sd) if embedder_arch(sd) == "resnet" else _vgg16_trunk(net, x, sd)
     net.out_slot = net.gem_l2n(f, float(sd["pool.p"].reshape(-1)[0]))
     net.feature_slot = net.output_nchw(f) if feature_tap else None
-    net.finalize()
+    if finalize:
+        net.finalize()
     return net
 
 
 HED_BLOCKS = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
 
 
-def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True, precision="f16"):
+def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True, precision="f16", finalize=True):
     """HedInterpolation.forward (hed.py:60-83); ``perm``/``in_affine`` fold the RgbToBgrPre + MeanStdPre wrappers
     (wrapper.py:351-364, :182-194) into the input pack kernel."""
     net = HipNet(device, precision)
@@ -398,7 +400,8 @@ def build_hed(sd, device, perm=None, in_affine=None, sigmoid=True, precision="f1
     net.out_slot = net.hed_head(
         feats, [sd["score%d.weight" % (k + 1)] for k in range(5)], [float(sd["score%d.bias" % (k + 1)]) for k in range(5)],
         [float(v) for v in sd["fusion.0.weight"].reshape(-1)], float(sd["fusion.0.bias"]), sigmoid)
-    net.finalize()
+    if finalize:
+        net.finalize()
     return net
 
 
