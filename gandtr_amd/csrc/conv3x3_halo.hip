@@ -33,7 +33,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 
 template <int PH, int BN, int WGM, int WGN>
 constexpr size_t halo_lds_bytes() {
-    constexpr size_t staging = 2 * (size_t)a_bytes(PH) + 2 * (size_t)BN * ROWB;
+    constexpr size_t staging = 2 * (size_t)a_bytes(PH) + 2 * (size_t)BN * ROWB + 1024;   // + (mean, rstd) of two chunks
     constexpr size_t epilogue = ((size_t)PH * 16 * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
     return staging > epilogue ? staging : epilogue;
 }
@@ -102,11 +102,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     // registers instead -- load 8 raw fp16 channels, x -> max((x - mean) * rstd, 0) in fp32, store to the same swizzled LDS
     // slot the DMA path would have filled.  One piece per tap step, written one step after it was issued.
     const bool norm_a = d.in_norm != nullptr;     // wave-uniform
-    float nmr[16];                                // (mean, rstd) of the 8 channels of the piece in flight
-    auto load_norm = [&](int chunk, int r) {
-        const float4* p = (const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64 + a_q[r] * 8) * 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const float4 v = p[k]; nmr[4 * k] = v.x; nmr[4 * k + 1] = v.y; nmr[4 * k + 2] = v.z; nmr[4 * k + 3] = v.w; }
+    // (mean, rstd) of the 64 channels of a chunk are staged once per chunk in LDS (512 B per stage, behind the weight
+    // stages) and read per piece from there: the per-piece channel group depends on the halo column swizzle, and fetching it
+    // from global memory per piece cost as many L2 bytes as the weight tile itself.
+    float* nlds = (float*)(smem + 2 * A_BYTES + 2 * B_BYTES);
+    auto stage_norm = [&](int chunk) {          // 32 lanes x float4 = 64 channels x (mean, rstd)
+        if (tid < 32) *(float4*)(nlds + (chunk & 1) * 128 + tid * 4) = *(const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64) * 2 + tid * 4);
     };
     auto load_piece = [&](int chunk, int r) -> f16x8 {
         f16x8 v;
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     auto store_piece = [&](int stage, int r, const f16x8& raw) {
         const int row = r * RPR + lrow;
         if (r >= NR || row >= HALO_ROWS_PAD) return;
+        float nmr[16];
+        const float4* np4 = (const float4*)(nlds + stage * 128 + a_q[r] * 16);      // stage == chunk & 1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float4 v = np4[k]; nmr[4 * k] = v.x; nmr[4 * k + 1] = v.y; nmr[4 * k + 2] = v.z; nmr[4 * k + 3] = v.w; }
         f16x8 o;
         const bool ok = (a_ok >> r) & 1u;                      // padded positions stay exactly zero
 #pragma unroll
@@ -159,8 +164,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     const int nchunks = d.Cin >> 6;
     const int total = nchunks * 9;
     if (norm_a) {
+        stage_norm(0);
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { load_norm(0, r); store_piece(0, r, load_piece(0, r)); }
+        for (int r = 0; r < NR; ++r) store_piece(0, r, load_piece(0, r));
     } else {
 #pragma unroll
         for (int r = 0; r < NR; ++r) issue_a(0, 0, r);
@@ -181,8 +188,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
         const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
         const bool halo_more = (c + 1 < nchunks) && t < NR && !norm_a;
         if (norm_a && c + 1 < nchunks) {
-            if (t >= 1 && t <= NR) store_piece((c + 1) & 1, t - 1, pend);     // uses the statistics loaded with that piece
-            if (t < NR) { load_norm(c + 1, t); pend = load_piece(c + 1, t); }
+            if (t == 0) stage_norm(c + 1);                                    // visible after the next barrier
+            if (t >= 1 && t <= NR) store_piece((c + 1) & 1, t - 1, pend);
+            if (t < NR) pend = load_piece(c + 1, t);
         }
         const int ty = (t * 21846) >> 16, tx = t - ty * 3;
         int a_ad[TM], b_ad[TN];
