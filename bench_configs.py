@@ -116,6 +116,17 @@ def main():
         x = synth.synth_input(5, (128, 3, 256, 256), 1.0).to(dev)
         r, ms = rate(lambda: chain(x), 128)
         out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1)}
+        # "next" row: retrieval scoring, revisitop-style: 200k database x 70 queries, D = 2048
+        from gandtr_amd import retrieval
+        import numpy as np
+        d, ndb, nq = 2048, 200000, 70
+        vecs = torch.nn.functional.normalize(torch.randn(ndb, d, device=dev), dim=1).t()      # D x Ndb view of [Ndb][D]
+        qv = torch.nn.functional.normalize(torch.randn(nq, d, device=dev), dim=1).t()
+        r, ms = rate(lambda: retrieval.scores_and_ranks(vecs, qv), nq, steps=5, warmup=2)
+        vc, qc = vecs[:, :20000].t().contiguous().cpu().numpy(), qv.cpu().numpy()
+        t0 = time.perf_counter(); s = np.dot(vc, qc); np.argsort(-s, axis=0); cpu = (time.perf_counter() - t0) * (ndb / 20000)
+        out["next_retrieval_200k_x_70_d2048"] = {"queries_per_s": r, "ms": ms, "gemm_gflop": round(2.0 * ndb * nq * d / 1e9, 1),
+                                                 "cpu_numpy_ms_extrapolated_from_20k": round(cpu * 1e3, 1)}
     print(json.dumps(out, indent=1))
 
 

@@ -49,6 +49,9 @@ SIGNATURES = {
     "gdt_net_profile_read": (c_int, [c_void_p, c_int, _IP, _IP, _IP, POINTER(c_double), POINTER(c_double)]),
     "gdt_ms_aggregate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gdt_whiten": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gdt_retrieval_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "gdt_retrieval_scores_ranks": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                           c_void_p]),
     "gdt_l2n_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 

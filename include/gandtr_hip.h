@@ -142,6 +142,18 @@ int gdt_whiten(const float* P, const float* m, const float* v, float* tmp, float
 /* x / (||x||_2 + eps) over rows of a [N][D] matrix (cirtorch layers/functional.py:130-131) */
 int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Retrieval scoring ("next" row of SURVEY.md section 8f: the consumer of the gathered descriptors)
+ * Replaces  scores = np.dot(vecs.T, qvecs); ranks = np.argsort(-scores, axis=0)
+ *   mdir/components/optim/score/cirscore.py:71-73; mdir/external/cirtorch/datasets/traindataset.py:246-279 (mm + sort).
+ * vecs [ndb][d] and qvecs [nq][d]: row-major fp32 descriptor blocks (d a power of two).  scores_t [nq][ndb] is the transpose of the
+ * reference's ndb x nq matrix; ranks_t int32 [nq][ndb] holds index_base + database index in order of decreasing score
+ * (NULL: scores only).  The GEMM runs in the f16x3 arithmetic (fp32-class accuracy).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int gdt_retrieval_workspace_bytes(int ndb, int nq, int d, int with_ranks, size_t* bytes);
+int gdt_retrieval_scores_ranks(const float* vecs, const float* qvecs, float* scores_t, int* ranks_t, int ndb, int nq, int d,
+                               int index_base, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,47 @@ def test_chunk_bounds_cover_batch():
             spans = [sharding.chunk_bounds(n, w, r)[:2] for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _np_scores_and_ranks(vecs, qvecs, with_ranks=True, index_base=0):
+    """numpy statement of the reference's scoring (cirscore.py:71-73), standing in for the HIP kernel on CPU ranks"""
+    import numpy as np
+    s = np.dot(vecs.numpy().T, qvecs.numpy())
+    r = np.argsort(-s, axis=0, kind="stable").astype(np.int32) + index_base
+    return torch.from_numpy(s), torch.from_numpy(r)
+
+
+def _topk_worker(rank, world, port, ndb, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from gandtr_amd import retrieval
+    retrieval.scores_and_ranks = _np_scores_and_ranks
+    vecs = synth._normal(5, "db", (32, ndb))
+    qv = synth._normal(6, "q", (32, 4))
+    lo, hi, _ = sharding.chunk_bounds(ndb, world, rank)
+    s, i = retrieval.sharded_topk(vecs[:, lo:hi], qv, k=5)
+    if rank == 0:
+        q.put((s.clone(), i.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ndb", [40, 7, 3])
+def test_sharded_topk_equals_global_ranking(ndb):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_topk_worker, args=(r, 2, port, ndb, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    s, i = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    vecs, qv = synth._normal(5, "db", (32, ndb)), synth._normal(6, "q", (32, 4))
+    ref_s, ref_r = _np_scores_and_ranks(vecs, qv)
+    k = min(5, ndb)
+    assert torch.equal(i[:k].long(), ref_r[:k].long())
+    assert torch.allclose(s[:k], torch.gather(ref_s, 0, ref_r[:k].long()))
