@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgandtr_hip.so")
+_LIB_PATH = os.environ.get("GANDTR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgandtr_hip.so")
 _lib = None
 
 GDT_OK, GDT_ERR_INVALID, GDT_ERR_HIP, GDT_ERR_WORKSPACE = 0, 1, 2, 3
