@@ -11,7 +11,9 @@
 //   8 wavefronts, v_mfma_f32_32x32x16_f16, two LDS stages for the halo (per chunk) and for the weights (per tap),
 //   one barrier per (chunk, tap) step, weight loads interleaved with the MFMAs, halo rounds spread over taps 0..5 of the
 //   previous chunk.  Same XOR swizzle (chunk' = chunk ^ ((row >> 1) & 7)) and the same epilogue as conv_igemm.hip.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gdt_common.h"
 
@@ -180,8 +182,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
 
     f16x8 afr[2][TM], bfr[2][TN];
     int c = 0, t = 0;                                   // chunk, tap of the current step
+    // diagnostic build only (GDT_CONV_STAMP=1 -> d.dbg & 16): cycles spent waiting at the step barrier vs in the step body
+    unsigned long long st_bar = 0, st_body = 0, st_prev = 0;
+    const bool stamp = (d.dbg & 16) != 0;
+    if (stamp) st_prev = __builtin_amdgcn_s_memtime();
     for (int s = 0; s < total; ++s) {
+        unsigned long long st0 = 0;
+        if (stamp) { st0 = __builtin_amdgcn_s_memtime(); st_body += st0 - st_prev; }
         __syncthreads();
+        if (stamp) { st_prev = __builtin_amdgcn_s_memtime(); st_bar += st_prev - st0; }
         const bool more = (s + 1 < total) && !(d.dbg & 1);
         int nc = c, nt = t + 1;
         if (nt == 9) { nt = 0; nc = c + 1; }
@@ -242,6 +251,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     }
 
     // ---------------------------------------------------------------- epilogue (fp16 NHWC through an LDS transpose)
+    unsigned long long st_loop_end = 0;
+    if (stamp) { st_loop_end = __builtin_amdgcn_s_memtime(); st_body += st_loop_end - st_prev; }
     if (d.dbg & 4) return;            // timing-only ablation
     constexpr int CP = BN + 8;
     __syncthreads();
@@ -305,6 +316,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
         }
         *(f16x8*)(d.out + off) = v;
     }
+    if (stamp && lane == 0 && d.stamp_out) {
+        const unsigned long long st_end = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = d.stamp_out + ((long)blockIdx.x * 8 + wave) * 4;
+        o[0] = st_bar; o[1] = st_body; o[2] = st_end - st_loop_end; o[3] = total;
+    }
 }
 
 template <int PH, int BN, int WGM, int WGN>
@@ -348,8 +364,28 @@ int gdt_launch_conv_halo(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
+    static const int want_stamp = [] { const char* e = getenv("GDT_CONV_STAMP"); return e ? atoi(e) : 0; }();
+    static unsigned long long* stamp_buf = nullptr;
+    const int stamp_blocks = (d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16) + 7) / 8 * 8 * (d.CoutPad / 256 ? d.CoutPad / 256 : 1);
+    if (want_stamp && d.CoutPad % 256 == 0) {            // diagnostic: per-wave cycle totals printed after a blocking sync
+        if (!stamp_buf) GDT_CHECK_HIP(hipMalloc((void**)&stamp_buf, (size_t)65536 * 8 * 4 * sizeof(unsigned long long)));
+        GDT_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)stamp_blocks * 8 * 4 * sizeof(unsigned long long), stream));
+        d.dbg |= 16; d.stamp_out = stamp_buf;
+        const int rc = launch_halo<16, 256, 2, 4>(d, stream);
+        GDT_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)stamp_blocks * 8 * 4);
+        GDT_CHECK_HIP(hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double bar = 0, body = 0, epi = 0, nw = 0, steps = 0;
+        for (size_t w = 0; w < h.size() / 4; ++w) if (h[w * 4 + 3]) { bar += h[w * 4]; body += h[w * 4 + 1]; epi += h[w * 4 + 2]; steps += h[w * 4 + 3]; nw += 1; }
+        fprintf(stderr, "[halo stamp] waves %.0f: per step: barrier %.0f cyc, body %.0f cyc; epilogue %.0f cyc per wave; steps/wave %.0f\n", nw,
+                bar / steps, body / steps, epi / nw, steps / nw);
+        return rc;
+    }
     static const int small = [] { const char* e = getenv("GDT_HALO_SMALL"); return e ? atoi(e) : 0; }();   // experiment knob
-    if (small && d.CoutPad % 128 == 0) return launch_halo<8, 128, 2, 2>(d, stream);      // two workgroups per CU
+    if (small == 1 && d.CoutPad % 128 == 0) return launch_halo<8, 128, 2, 2>(d, stream);  // two workgroups per CU
+    // 16 wavefronts (64x64 per wave, 4 per SIMD): equal to the 8-wave form on plain layers (0.281 vs 0.283 ms), faster when the
+    // InstanceNorm of the producer is applied while staging (0.299 vs 0.316 ms): more waves hide the register-staged halo path
+    if ((small == 2 || d.in_norm) && d.CoutPad % 256 == 0) return launch_halo<16, 256, 4, 4>(d, stream);
     if (d.CoutPad % 256 == 0) return launch_halo<16, 256, 2, 4>(d, stream);
     if (d.CoutPad % 128 == 0) return launch_halo<16, 128, 4, 2>(d, stream);
     return launch_halo<16, 64, 8, 1>(d, stream);

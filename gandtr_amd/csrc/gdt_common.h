@@ -64,6 +64,7 @@ struct ConvLaunch {
     int act;                      // out_f32 only: 0 none, 1 tanh, 2 sigmoid
     int M;                        // N * OHg * OWg
     int dbg;                      // timing-only ablation knob (env GDT_CONV_DBG): 1 skip staging loads, 2 skip MFMAs
+    unsigned long long* stamp_out;  // diagnostic builds only (GDT_CONV_STAMP): per-wave s_memtime totals
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
 };
 
