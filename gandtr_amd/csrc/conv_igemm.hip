@@ -345,6 +345,12 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
         if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
     }
     GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");
+    // under-filled launches (small batches): narrower N tiles put more workgroups on the chip; the K loop is what bounds them
+    const long tiles128 = ((long)d.M + 127) / 128;
+    if (bn == 128 && tiles128 * (d.CoutPad / 128) < 192 && d.CoutPad % 64 == 0 && force_tile == 0) {
+        *variant = 128064;
+        return launch_cfg<128, 64, 2, 2>(d, stream);
+    }
     *variant = 128000 + bn;
     if (bn == 128) return launch_cfg<128, 128, 2, 2>(d, stream);
     if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, stream);
