@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "conv_epilogue.h"
 #include "gdt_common.h"
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -36,7 +37,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 template <int PH, int BN, int WGM, int WGN>
 constexpr size_t halo_lds_bytes() {
     constexpr size_t staging = 2 * (size_t)a_bytes(PH) + 2 * (size_t)BN * ROWB + 1024;   // + (mean, rstd) of two chunks
-    constexpr size_t epilogue = ((size_t)PH * 16 * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+    constexpr size_t epilogue = conv_epilogue_lds_bytes<PH * 16, BN, WGM, WGN, WGM * WGN * 64>();
     return staging > epilogue ? staging : epilogue;
 }
 
@@ -254,68 +255,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     unsigned long long st_loop_end = 0;
     if (stamp) { st_loop_end = __builtin_amdgcn_s_memtime(); st_body += st_loop_end - st_prev; }
     if (d.dbg & 4) return;            // timing-only ablation
-    constexpr int CP = BN + 8;
-    __syncthreads();
-    f16* Ct = (f16*)smem;
-    const bool relu_now = d.relu && !d.res;
-    constexpr int STATS_OFF = (BM * CP * 2 + 255) / 256 * 256;
-    float* sl = (float*)(smem + STATS_OFF);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = wn * WTN + j * 32 + fr;
-        const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                float v = acc[i][j][e] + bv;
-                s1 += v; s2 += v * v;
-                if (relu_now) v = fmaxf(v, 0.f);
-                Ct[row * CP + col] = (f16)v;
-            }
-        if (d.stats) {
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (fh == 0) { sl[(wm * BN + col) * 2 + 0] = s1; sl[(wm * BN + col) * 2 + 1] = s2; }
-        }
-    }
-    __syncthreads();
-    constexpr int RT = BM / 128, WPR = WGM / RT;     // 128-row statistics records per tile, wave rows per record
-    static_assert(WGM % RT == 0 && BN * RT <= NT, "statistics record layout");
-    if (d.stats && tid < BN * RT) {
-        const int rec = tid / BN, col = tid % BN;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
-        const int gcol = tile_n * BN + col;
-        if (gcol < d.Cout) {
-            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
-            dst[0] = s1; dst[d.Cout] = s2;
-        }
-    }
-    constexpr int CPR = BN / 8, NCH = BM * CPR / NT;
-    if (d.dbg & 8) return;            // timing-only ablation: LDS transpose done, no global stores
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int id = k * NT + tid;
-        const int row = id / CPR, c8 = id % CPR;
+    conv_epilogue_f16<BM, BN, WGM, WGN, NT, TM, TN>(d, acc, smem, tile_m, tile_n, [&](int row, bool& ok) -> long {
         const int y = y0 + (row >> 4), x = x0 + (row & 15);
-        const int col = tile_n * BN + c8 * 8;
-        if (y >= d.H || x >= d.W || col >= d.Cout) continue;
-        const long off = (((long)n * d.H + y) * d.W + x) * d.Cout + col;
-        f16x8 v = *(const f16x8*)(Ct + row * CP + c8 * 8);
-        if (d.res) {
-            const f16x8 rv = *(const f16x8*)(d.res + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float tv = (float)v[e] + (float)rv[e];
-                if (d.relu) tv = fmaxf(tv, 0.f);
-                v[e] = (f16)tv;
-            }
-        }
-        *(f16x8*)(d.out + off) = v;
-    }
+        ok = (y < d.H) & (x < d.W);
+        return ((long)n * d.H + y) * d.W + x;
+    });
     if (stamp && lane == 0 && d.stamp_out) {
         const unsigned long long st_end = __builtin_amdgcn_s_memtime();
         unsigned long long* o = d.stamp_out + ((long)blockIdx.x * 8 + wave) * 4;

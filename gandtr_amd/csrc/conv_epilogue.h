@@ -1,0 +1,87 @@
+// fp16 NHWC epilogue shared by conv_igemm.hip and conv3x3_halo.hip.
+//
+// Input: the wave's 32x32 MFMA accumulator tiles acc[TM][TN] (C layout of v_mfma_f32_32x32x16: column = lane & 31, row =
+// (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  Steps: + bias (folded BatchNorm shift), optional ReLU, fp16 -> LDS transpose
+// so that every lane stores 16 contiguous bytes; per-128-row InstanceNorm partial statistics (sum, sum of squares) from the
+// fp32 values with a fixed reduction order (deterministic); optional residual add (+ ReLU) in fp32 on the way out.
+// `pixel_of(row, ok)` maps a tile row to the output pixel index (n * OH * OW + y * OW + x) and says whether it exists.
+#pragma once
+#include "gdt_common.h"
+
+template <int BM, int BN, int WGM, int WGN, int NT>
+constexpr size_t conv_epilogue_lds_bytes() {
+    return ((size_t)BM * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NT, int TM, int TN, typename PixelOf>
+__device__ __forceinline__ void conv_epilogue_f16(const ConvLaunch& d, const f32x16 (&acc)[TM][TN], char* smem, int tile_m, int tile_n,
+                                                  PixelOf pixel_of) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int CP = BN + 8;                                      // padded C-tile row (halves)
+    constexpr int STATS_OFF = (BM * CP * 2 + 255) / 256 * 256;      // [WGM][BN][2] floats behind the C tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, fr = lane & 31, fh = lane >> 5;
+    __syncthreads();                                                // all MFMA reads of the staging buffers are done
+    f16* Ct = (f16*)smem;
+    float* sl = (float*)(smem + STATS_OFF);
+    const bool relu_now = d.relu && !d.res;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + fr;
+        const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float v = acc[i][j][e] + bv;
+                s1 += v; s2 += v * v;
+                if (relu_now) v = fmaxf(v, 0.f);
+                Ct[row * CP + col] = (f16)v;
+            }
+        if (d.stats) {      // per-lane column sums over the wave's rows, the two half-waves combined
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (fh == 0) { sl[(wm * BN + col) * 2 + 0] = s1; sl[(wm * BN + col) * 2 + 1] = s2; }
+        }
+    }
+    __syncthreads();
+    constexpr int RT = BM / 128;            // 128-row statistics records per tile
+    constexpr int WPR = WGM / RT;           // wave rows per record
+    static_assert(BM % 128 == 0 && WGM % RT == 0 && BN * RT <= NT, "statistics record layout");
+    if (d.stats && tid < BN * RT) {
+        const int rec = tid / BN, col = tid % BN;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
+        const int gcol = tile_n * BN + col;
+        if (gcol < d.Cout) {
+            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
+            dst[0] = s1; dst[d.Cout] = s2;
+        }
+    }
+    if (d.dbg & 8) return;                  // timing-only ablation: no global stores
+    constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
+    constexpr int NCH = BM * CPR / NT;      // chunks per thread
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int id = c * NT + tid;
+        const int row = id / CPR, c8 = id % CPR;
+        const int col = tile_n * BN + c8 * 8;
+        bool ok;
+        const long pix = pixel_of(row, ok);
+        if (!ok || col >= d.Cout) continue;
+        const long off = pix * d.Cout + col;
+        f16x8 v = *(const f16x8*)(Ct + row * CP + c8 * 8);
+        if (d.res) {
+            const f16x8 rv = *(const f16x8*)(d.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)v[e] + (float)rv[e];
+                if (d.relu) t = fmaxf(t, 0.f);
+                v[e] = (f16)t;
+            }
+        }
+        *(f16x8*)(d.out + off) = v;
+    }
+}

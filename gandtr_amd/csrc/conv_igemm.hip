@@ -15,6 +15,7 @@
 // reads.  Two LDS stages, one barrier per K-step: the loads of step k+1 are in flight while step k computes.
 #include <cstdlib>
 
+#include "conv_epilogue.h"
 #include "gdt_common.h"
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -214,80 +215,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
         return;
     }
 
-    // fp16 NHWC output: transpose through LDS so that every lane stores 16 contiguous bytes
-    constexpr int CP = BN + 8;   // padded row (halves)
-    __syncthreads();             // all MFMA reads of the staging buffers are done
-    f16* Ct = (f16*)smem;
-    const bool relu_now = d.relu && !d.res;
-    constexpr int STATS_OFF = (BM * CP * 2 + 255) / 256 * 256;     // [WGM][BN][2] floats behind the C tile
-    float* sl = (float*)(smem + STATS_OFF);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = wn * WTN + j * 32 + fr;
-        const float bv = d.bias ? d.bias[tile_n * BN + col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                float v = acc[i][j][e] + bv;
-                s1 += v; s2 += v * v;
-                if (relu_now) v = fmaxf(v, 0.f);
-                Ct[row * CP + col] = (f16)v;
-            }
-        if (d.stats) {
-            // InstanceNorm partial statistics of this tile from the fp32 accumulators: per-lane column sums over the
-            // wave's rows, the two half-waves combined, then a fixed-order sum over the wave rows below (deterministic)
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (fh == 0) { sl[(wm * BN + col) * 2 + 0] = s1; sl[(wm * BN + col) * 2 + 1] = s2; }
-        }
-    }
-    __syncthreads();
-    constexpr int RT = BM / 128;            // 128-row statistics records per tile
-    constexpr int WPR = WGM / RT;           // wave rows per record
-    static_assert(BM % 128 == 0 && WGM % RT == 0 && BN * RT <= NT, "statistics record layout");
-    if (d.stats && tid < BN * RT) {
-        const int rec = tid / BN, col = tid % BN;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
-        const int gcol = tile_n * BN + col;
-        if (gcol < d.Cout) {
-            float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
-            dst[0] = s1; dst[d.Cout] = s2;
-        }
-    }
-    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
-    constexpr int NCH = BM * CPR / NT;          // chunks per thread
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int id = c * NT + tid;
-        const int row = id / CPR, c8 = id % CPR;
+    // fp16 NHWC output (conv_epilogue.h): LDS transpose, fused InstanceNorm statistics, residual add
+    conv_epilogue_f16<BM, BN, WGM, WGN, NT, TM, TN>(d, acc, smem, tile_m, tile_n, [&](int row, bool& ok) -> long {
         const int m = tile_m * BM + row;
-        const int col = tile_n * BN + c8 * 8;
-        if (m >= d.M || col >= d.Cout) continue;
-        const int n = m / hw_g, rem = m - n * hw_g;
+        ok = m < d.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / hw_g, rem = mm - n * hw_g;
         const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
-        const long off = ((long)n * ohw + (long)(oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox) * d.Cout + col;
-        f16x8 v = *(const f16x8*)(Ct + row * CP + c8 * 8);
-        if (d.res) {
-            const f16x8 rv = *(const f16x8*)(d.res + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = (float)v[e] + (float)rv[e];
-                if (d.relu) t = fmaxf(t, 0.f);
-                v[e] = (f16)t;
-            }
-        }
-        *(f16x8*)(d.out + off) = v;
-    }
+        return (long)n * ohw + (long)(oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox;
+    });
 }
 
 template <int BM, int BN, int WGM, int WGN>
 constexpr size_t lds_bytes() {
     constexpr size_t staging = 2 * (size_t)(BM + BN) * ROWB;
-    constexpr size_t epilogue = ((size_t)BM * (BN + 8) * 2 + 255) / 256 * 256 + (size_t)WGM * BN * 8;
+    constexpr size_t epilogue = conv_epilogue_lds_bytes<BM, BN, WGM, WGN, WGM * WGN * 64>();
     return staging > epilogue ? staging : epilogue;
 }
 
