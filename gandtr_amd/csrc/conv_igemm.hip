@@ -30,7 +30,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool NORM = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLaunch d) {
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 wavefronts)
     constexpr int RPR = NT / 8;                       // tile rows staged per loader round (8 lanes x 16 B per row)
@@ -103,6 +103,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
         const f16* src = d.in + (((long)pix << (d.lc8 + 3)) + n_c8 * 8);
         glds16(ok ? src : d.zeros, As + (r * RPR + wave * 8) * ROWB);
     };
+    // Fused InstanceNorm(+ReLU) of the producer for 64-channel inputs (generator: stem -> first down conv, last up conv -> head;
+    // p2p_networks.py:271-272, :299-300): the A operand goes through registers -- raw fp16 chunk, x -> max((x-mean)*rstd, 0)
+    // in fp32, ds_write_b128 into the slot the DMA path would have filled.  With Cin == 64 a lane's channel group (q) is
+    // the same in every K-step, and the tile lies inside one image, so its 8 (mean, rstd) pairs are loaded once.
+    constexpr bool norm_a = NORM;                       // separate instantiation: keeps the DMA-only form lean
+    float nmr[16];
+    if constexpr (norm_a) {
+        const int n_img = (tile_m * BM) / hw_g;
+        const float4* p4 = (const float4*)(d.in_norm + ((long)n_img * d.Cin + q * 8) * 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float4 v = p4[k]; nmr[4 * k] = v.x; nmr[4 * k + 1] = v.y; nmr[4 * k + 2] = v.z; nmr[4 * k + 3] = v.w; }
+    }
+    f16x8 areg[AR]; unsigned areg_ok = 0;
+    auto load_a_regs = [&]() {                          // uses the decoded (tap, chunk) of the NEXT K-step
+        areg_ok = 0;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int iy = a_iy0[r] + n_dy, ix = a_ix0[r] + n_dx;
+            const int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+            const int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+            const bool ok = n_tap_ok & (((a_valid >> r) & 1u) != 0) & (inb | refl);
+            const int pix = a_base[r] + ry * d.W + rx;
+            const f16* src = ok ? d.in + (((long)pix << (d.lc8 + 3)) + n_c8 * 8) : d.zeros;
+            areg[r] = *(const f16x8*)src;
+            areg_ok |= (ok ? 1u : 0u) << r;
+        }
+    };
+    auto store_a_regs = [&](int stage) {
+        char* As = smem + stage * A_BYTES;
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            f16x8 o;
+            const bool ok = (areg_ok >> r) & 1u;        // padded / out-of-range positions stay exactly zero
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = ((float)areg[r][e] - nmr[2 * e]) * nmr[2 * e + 1];
+                if (d.in_relu) f = fmaxf(f, 0.f);
+                o[e] = ok ? (f16)f : (f16)0.f;
+            }
+            *(f16x8*)(As + (r * RPR + lrow) * ROWB + ((lane & 7) << 4)) = o;
+        }
+    };
     auto issue_b = [&](int ks, int stage, int r) {
         char* Bs = smem + 2 * A_BYTES + stage * B_BYTES;
         glds16(b_src + ((long)r * RPR * d.Kpad + ks * BK), Bs + (r * RPR + wave * 8) * ROWB);
@@ -131,8 +174,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
     }
 
     decode(0);
+    if constexpr (norm_a) { load_a_regs(); store_a_regs(0); }
+    else {
 #pragma unroll
-    for (int r = 0; r < AR; ++r) issue_a(0, r);
+        for (int r = 0; r < AR; ++r) issue_a(0, r);
+    }
 #pragma unroll
     for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
 
@@ -144,6 +190,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
         const bool more = (ks + 1 < d.nk) && !(d.dbg & 1);
         const int nst = (ks + 1) & 1;
         if (more) decode(ks + 1);
+        if constexpr (norm_a) { if (more) load_a_regs(); }   // issue-early; normalised and written after this step's MFMAs
         const char* As = smem + (ks & 1) * A_BYTES;
         const char* Bs = smem + 2 * A_BYTES + (ks & 1) * B_BYTES;
         if (d.dbg & 2) {
@@ -169,7 +216,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(Bs + b_off[j] + ((ch ^ b_sw[j]) << 4));
             }
-            if (more) {
+            if (!norm_a && more) {
 #pragma unroll
                 for (int r = kk * APK; r < (kk + 1) * APK && r < AR; ++r) issue_a(nst, r);
             }
@@ -185,6 +232,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (norm_a) { if (more) store_a_regs(nst); }
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -233,7 +281,7 @@ constexpr size_t lds_bytes() {
     return staging > epilogue ? staging : epilogue;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool NORM = false>
 int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     const int ntm = (d.M + BM - 1) / BM, ntn = d.CoutPad / BN;
     const int ntm8 = (ntm + 7) / 8 * 8;
@@ -242,17 +290,23 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     if (lds > 64 * 1024) {
         static bool attr_set = false;     // one attribute call per template instantiation
         if (!attr_set) {
-            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WGM, WGN>,
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WGM, WGN, NORM>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, NORM>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
 }  // namespace
+
+// the generic kernel can apply the producer's InstanceNorm while staging when a lane's channel group is step-invariant
+// (Cin == 64) and a tile never straddles two images
+bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d) {
+    return d.Cin == 64 && (d.OHg * d.OWg) % 256 == 0 && d.M % 256 == 0;
+}
 
 int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
@@ -271,6 +325,13 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
                              "fused InstanceNorm statistics need whole 128-row tiles per image and a plain conv epilogue");
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
+    if (d.in_norm && !gdt_conv_halo_eligible(d))
+        GDT_REQUIRE(gdt_conv_igemm_norm_eligible(d), "fused input normalisation needs Cin == 64 and whole 256-row tiles per image here");
+    if (d.in_norm && !gdt_conv_halo_eligible(d)) {      // generic kernel with the producer's InstanceNorm folded into the A staging
+        if (bn == 128) { *variant = 256128; return launch_cfg<256, 128, 4, 2, true>(d, stream); }
+        if (bn == 64) { *variant = 128064; return launch_cfg<128, 64, 2, 2, true>(d, stream); }
+        *variant = 128032; return launch_cfg<128, 32, 4, 1, true>(d, stream);
+    }
     if (gdt_conv_halo_eligible(d)) { *variant = 900000 + (d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64)); return gdt_launch_conv_halo(d, stream); }
     if (d.pad_reflect) {
         const int pady = d.dy0 < 0 ? -d.dy0 : 0, padx = d.dx0 < 0 ? -d.dx0 : 0;
@@ -282,8 +343,8 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     static const int force_tile = [] { const char* e = getenv("GDT_CONV_TILE"); return e ? atoi(e) : 0; }();   // test knob
     const long min_blocks = force_tile == 256 ? 1 : 512;
     static const int min_nk = [] { const char* e = getenv("GDT_CONV_MINK"); return e ? atoi(e) : 0; }();
-    if (force_tile != 128 && !d.in_norm && (d.nk >= min_nk || force_tile == 256)) {
-        if (d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
+    if (force_tile != 128 && (d.nk >= min_nk || force_tile == 256)) {
+        if (!d.in_norm && d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
         if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
     }
     GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");

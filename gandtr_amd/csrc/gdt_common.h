@@ -70,6 +70,7 @@ struct ConvLaunch {
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>
 int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
+bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d);    // conv_igemm.hip: fused input InstanceNorm in the generic kernel
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32

@@ -219,13 +219,16 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
 
         const int k = consumer_op[oj.out];
         const Op& ok = ops[k];
-        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || ok.rowsplit || ok.cd.transposed || ok.cd.out_f32_nchw) continue;
+        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || ok.cd.transposed) continue;
+        if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
         ConvLaunch d{};
         conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
+        if (ok.rowsplit) { d.Cout = ok.rs_cout8; d.out_f32 = nullptr; }
         d.w_lo = net->precision ? (const f16*)net : nullptr;                       // non-null marker only
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
-        const bool halo = net->precision ? gdt_conv_halo_x3_eligible(d) : gdt_conv_halo_eligible(d);
-        if (halo) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; }
+        d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
+        const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d) : (gdt_conv_halo_eligible(d) || gdt_conv_igemm_norm_eligible(d));
+        if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; }
     }
 
     // ---- pass 3: liveness + first-fit layout
