@@ -183,6 +183,18 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
         const int col = tile_n * BN + lcol;
         const float bv = d.bias ? d.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        float rr[TM][16];                      // residual values of this column: all loads issued before any is consumed
+        if (resp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    const int y = y0 + (row >> 4), x = x0 + (row & 15);
+                    const bool ok = y < d.H && x < d.W && col < d.Cout;
+                    rr[i][e] = resp[ok ? (((long)n * d.H + y) * d.W + x) * d.Cout + col : 0];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 const int y = y0 + (row >> 4), x = x0 + (row & 15);
                 if (y >= d.H || x >= d.W || col >= d.Cout) continue;
                 const long off = (((long)n * d.H + y) * d.W + x) * d.Cout + col;
-                if (resp) v += resp[off];
+                if (resp) v += rr[i][e];
                 if (d.relu) v = fmaxf(v, 0.f);
                 outp[off] = v;
             }

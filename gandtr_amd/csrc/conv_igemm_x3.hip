@@ -186,6 +186,22 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
         const int col = tile_n * BN + lcol;
         const float bv = (d.bias && col < d.CoutPad) ? d.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
+        float rr[TM][16];                      // residual values of this column: all loads issued before any is consumed
+        if (resp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    const int m = tile_m * BM + row;
+                    const bool ok = m < d.M && col < d.Cout;
+                    const int mm = ok ? m : 0;
+                    const int n = mm / hw_g, rem = mm - n * hw_g;
+                    const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+                    const long off = ((long)n * ohw + (long)(oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox) * d.Cout + (ok ? col : 0);
+                    rr[i][e] = resp[ok ? off : 0];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
                     d.out_f32[((long)n * d.Cout + col) * ohw + opix] = v;
                 } else {
                     const long off = ((long)n * ohw + opix) * d.Cout + col;
-                    if (resp) v += resp[off];
+                    if (resp) v += rr[i][e];
                     if (d.relu) v = fmaxf(v, 0.f);
                     outp[off] = v;
                 }
