@@ -63,13 +63,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + PH - 1) / PH;
     const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
     int tile_m, tile_n;
-    {
-        const int b = blockIdx.x;
-        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
-        tile_m = grp * 8 + (rem & 7);
-        tile_n = rem >> 3;
-        if (tile_m >= ntm) return;
-    }
+    if (!gdt_tile_of_block(blockIdx.x, ntm, ntn, tile_m, tile_n)) return;      // XCD-chunked, see gdt_common.h
     const int n = tile_m / tpi, tr = tile_m - n * tpi;
     const int y0 = (tr / tiles_x) * PH, x0 = (tr % tiles_x) << 4;
 
@@ -270,7 +264,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
 template <int PH, int BN, int WGM, int WGN>
 int launch_halo(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
-    const int ntm8 = (tiles + 7) / 8 * 8;
     constexpr size_t lds = halo_lds_bytes<PH, BN, WGM, WGN>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
@@ -279,7 +272,7 @@ int launch_halo(const ConvLaunch& d, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<PH, BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<PH, BN, WGM, WGN>), dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

@@ -38,13 +38,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
     const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + 15) >> 4;
     const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
     int tile_m, tile_n;
-    {
-        const int b = blockIdx.x;
-        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
-        tile_m = grp * 8 + (rem & 7);
-        tile_n = rem >> 3;
-        if (tile_m >= ntm) return;
-    }
+    if (!gdt_tile_of_block(blockIdx.x, ntm, ntn, tile_m, tile_n)) return;      // XCD-chunked, see gdt_common.h
     const int n = tile_m / tpi, tr = tile_m - n * tpi;
     const int y0 = (tr / tiles_x) << 4, x0 = (tr % tiles_x) << 4;
 
@@ -247,7 +241,6 @@ bool gdt_conv_halo_x3_eligible(const ConvLaunch& d) {
 
 int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16), ntn = d.CoutPad / BN;
-    const int ntm8 = (tiles + 7) / 8 * 8;
     constexpr size_t lds = 2 * (size_t)STAGE_A + 2 * (size_t)STAGE_B;
     static_assert(lds <= 160 * 1024 && (size_t)4 * BN * 8 <= lds, "LDS budget");
     static bool attr_set = false;
@@ -255,7 +248,7 @@ int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_halo_x3_kernel, dim3(ntm8 * ntn), dim3(NT), lds, stream, d);
+    hipLaunchKernelGGL(conv3x3_halo_x3_kernel, dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(NT), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

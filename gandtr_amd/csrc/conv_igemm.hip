@@ -44,18 +44,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_kernel(const ConvLa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // block -> (tile_m, tile_n): N-tiles of the same M-tile are 8 blocks apart, i.e. on the same XCD under the
-    // observed round-robin dispatch, so the shared A rows are served by one L2 (speed only, never correctness).
     const int ntn = d.CoutPad / BN;
     int tile_m, tile_n;
-    {
-        const int b = blockIdx.x;
-        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
-        tile_m = grp * 8 + (rem & 7);
-        tile_n = rem >> 3;
-        const int ntm = (d.M + BM - 1) / BM;
-        if (tile_m >= ntm) return;   // grid is padded to a multiple of 8 M-tiles
-    }
+    if (!gdt_tile_of_block(blockIdx.x, (d.M + BM - 1) / BM, ntn, tile_m, tile_n)) return;      // XCD-chunked, see gdt_common.h
 
     // ---- per-thread loader state: this thread stages 16-byte chunk (lane & 7) of rows r = round*RPR + wave*8 + lane/8
     const int lrow = wave * 8 + (lane >> 3);
@@ -284,7 +275,6 @@ constexpr size_t lds_bytes() {
 template <int BM, int BN, int WGM, int WGN, bool NORM = false>
 int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     const int ntm = (d.M + BM - 1) / BM, ntn = d.CoutPad / BN;
-    const int ntm8 = (ntm + 7) / 8 * 8;
     constexpr size_t lds = lds_bytes<BM, BN, WGM, WGN>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
     if (lds > 64 * 1024) {
@@ -295,7 +285,7 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, NORM>), dim3(ntm8 * ntn), dim3(WGM * WGN * 64), lds, stream, d);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, NORM>), dim3(gdt_grid_for_tiles(ntm, ntn)), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -346,6 +336,7 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     if (force_tile != 128 && (d.nk >= min_nk || force_tile == 256)) {
         if (!d.in_norm && d.CoutPad % 256 == 0 && tiles256 * (d.CoutPad / 256) >= min_blocks) { *variant = 256256; return launch_cfg<256, 256, 2, 4>(d, stream); }
         if (bn == 128 && tiles256 * (d.CoutPad / 128) >= min_blocks) { *variant = 256128; return launch_cfg<256, 128, 4, 2>(d, stream); }
+        if (bn == 64 && tiles256 * (d.CoutPad / 64) >= 2 * min_blocks) { *variant = 256064; return launch_cfg<256, 64, 4, 2>(d, stream); }
     }
     GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");
     // under-filled launches (small batches): narrower N tiles put more workgroups on the chip; the K loop is what bounds them

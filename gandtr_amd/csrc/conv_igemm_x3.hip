@@ -45,13 +45,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
 
     const int ntn = d.CoutPad / BN;
     int tile_m, tile_n;
-    {
-        const int b = blockIdx.x;
-        const int grp = b / (8 * ntn), rem = b % (8 * ntn);
-        tile_m = grp * 8 + (rem & 7);
-        tile_n = rem >> 3;
-        if (tile_m >= (d.M + BM - 1) / BM) return;
-    }
+    if (!gdt_tile_of_block(blockIdx.x, (d.M + BM - 1) / BM, ntn, tile_m, tile_n)) return;
 
     // ---- A staging state: this thread owns 4-channel group c4 = tid & 7 of rows (tid >> 3) + 32*i
     const int c4 = tid & 7, arow = tid >> 3;
@@ -249,10 +243,9 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
 template <int BN, int WGM, int WGN>
 int launch_x3(const ConvLaunch& d, hipStream_t stream) {
     const int ntm = (d.M + 127) / 128, ntn = d.CoutPad / BN;
-    const int ntm8 = (ntm + 7) / 8 * 8;
     constexpr size_t lds = 2 * (size_t)(2 * 128 * ROWB + 2 * BN * ROWB);
     static_assert(lds <= 64 * 1024 && (size_t)WGM * BN * 8 <= lds, "LDS budget");
-    hipLaunchKernelGGL((conv_igemm_x3_kernel<BN, WGM, WGN>), dim3(ntm8 * ntn), dim3(256), lds, stream, d);
+    hipLaunchKernelGGL((conv_igemm_x3_kernel<BN, WGM, WGN>), dim3(gdt_grid_for_tiles(ntm, ntn)), dim3(256), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

@@ -69,6 +69,21 @@ struct ConvLaunch {
 };
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>
+// Workgroup -> (M tile, N tile).  Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md), each
+// with a private L2.  Every XCD therefore gets ONE contiguous span of M tiles: spatially adjacent tiles (which share input
+// rows through the kernel taps / halos) and the N tiles of one M tile (which share the whole A operand) meet in the same L2.
+// With tiles interleaved over the XCDs instead, the 7x1 head conv of the generator fetched its 537 MB input 6.7 times
+// (FETCH_SIZE 3.6 GB per launch).  Placement only affects speed, never results.  Grid size: 8 * ceil(ntm / 8) * ntn.
+__device__ __forceinline__ bool gdt_tile_of_block(int b, int ntm, int ntn, int& tile_m, int& tile_n) {
+    const int mchunk = (ntm + 7) >> 3;
+    const int xcd = b & 7, j = b >> 3;
+    tile_n = j % ntn;
+    const int lm = j / ntn;
+    tile_m = xcd * mchunk + lm;
+    return lm < mchunk && tile_m < ntm;
+}
+inline int gdt_grid_for_tiles(int ntm, int ntn) { return 8 * ((ntm + 7) / 8) * ntn; }
+
 int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
 bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d);    // conv_igemm.hip: fused input InstanceNorm in the generic kernel
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
