@@ -74,12 +74,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     const int lrow = tid >> 3;                          // 0..RPR-1
     const int q = (lane & 7) ^ ((lrow >> 1) & 7);       // weight tile: generic swizzle
     const bool refl = d.pad_reflect != 0;
-    int a_pix[NR], a_q[NR]; unsigned a_ok = 0;
+    int a_pix[NR], a_q[NR]; unsigned a_ok = 0, a_int = 0;     // a_int: piece is an interior pixel of this patch (inside the image)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int h = r * RPR + lrow;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
         a_q[r] = (lane & 7) ^ ((hx >> 1) & 7);
+        a_int |= (((hy >= 1) & (hy <= PH) & (hx >= 1) & (hx <= 16) & (y0 - 1 + hy < d.H) & (x0 - 1 + hx < d.W)) ? 1u : 0u) << r;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
         int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
@@ -104,7 +105,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
     // from global memory per piece cost as many L2 bytes as the weight tile itself.
     float* nlds = (float*)(smem + 2 * A_BYTES + 2 * B_BYTES);
     auto stage_norm = [&](int chunk) {          // 32 lanes x float4 = 64 channels x (mean, rstd)
-        if (tid < 32) *(float4*)(nlds + (chunk & 1) * 128 + tid * 4) = *(const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64) * 2 + tid * 4);
+        if (tid < 32) {                         // kept as (scale, shift) = (rstd, -mean * rstd): one fma per element
+            const float4 v = *(const float4*)(d.in_norm + ((long)n * d.Cin + chunk * 64) * 2 + tid * 4);
+            *(float4*)(nlds + (chunk & 1) * 128 + tid * 4) = make_float4(v.y, -v.x * v.y, v.w, -v.z * v.w);
+        }
     };
     auto load_piece = [&](int chunk, int r) -> f16x8 {
         f16x8 v;
@@ -114,7 +118,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
             v = *(const f16x8*)(d.in + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8));
         return v;
     };
-    auto store_piece = [&](int stage, int r, const f16x8& raw) {
+    auto load_res_piece = [&](int chunk, int r) -> f16x8 {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (f16)0.f;
+        if (d.in_res && r < NR && r * RPR + lrow < HALO_ROWS_PAD && ((a_ok >> r) & 1u))
+            v = *(const f16x8*)(d.in_res + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8));
+        return v;
+    };
+    auto store_piece = [&](int stage, int chunk, int r, const f16x8& raw, const f16x8& resv) {
         const int row = r * RPR + lrow;
         if (r >= NR || row >= HALO_ROWS_PAD) return;
         float nmr[16];
@@ -125,11 +137,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
         const bool ok = (a_ok >> r) & 1u;                      // padded positions stay exactly zero
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = ((float)raw[e] - nmr[2 * e]) * nmr[2 * e + 1];
+            float f = fmaf((float)raw[e], nmr[2 * e], nmr[2 * e + 1]);
             if (d.in_relu) f = fmaxf(f, 0.f);
+            if (d.in_res) f += (float)resv[e];
             o[e] = ok ? (f16)f : (f16)0.f;
         }
         *(f16x8*)(smem + stage * A_BYTES + row * ROWB + ((lane & 7) << 4)) = o;
+        // the transformed tensor itself (e.g. the ResnetBlock output) is materialised by the patch that owns the pixel
+        if (d.in_out && tile_n == 0 && ((a_int >> r) & 1u))
+            *(f16x8*)(d.in_out + (((long)a_pix[r] << (d.lc8 + 3)) + (chunk * 8 + a_q[r]) * 8)) = o;
     };
     auto issue_b = [&](int koff, int stage, int r) {
         glds16(b_src + ((long)r * RPR * d.Kpad + koff), smem + 2 * A_BYTES + stage * B_BYTES + (r * RPR + wave * 8) * ROWB);
@@ -164,16 +180,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
         stage_norm(0);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < NR; ++r) store_piece(0, r, load_piece(0, r));
+        for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(0, r), load_res_piece(0, r));
     } else {
 #pragma unroll
         for (int r = 0; r < NR; ++r) issue_a(0, 0, r);
     }
 #pragma unroll
     for (int r = 0; r < BR; ++r) issue_b(0, 0, r);
-    f16x8 pend;
+    f16x8 pend, pend_res;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) pend[e] = (f16)0.f;
+    for (int e = 0; e < 8; ++e) { pend[e] = (f16)0.f; pend_res[e] = (f16)0.f; }
 
     f16x8 afr[2][TM], bfr[2][TN];
     int c = 0, t = 0;                                   // chunk, tap of the current step
@@ -191,11 +207,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
         if (nt == 9) { nt = 0; nc = c + 1; }
         const int nkoff = nt * d.Cin + (nc << 6);         // K offset of the next step's weight slice
         const bool halo_more = (c + 1 < nchunks) && t < NR && !norm_a;
-        if (norm_a && c + 1 < nchunks) {
-            if (t == 0) stage_norm(c + 1);                                    // visible after the next barrier
-            if (t >= 1 && t <= NR) store_piece((c + 1) & 1, t - 1, pend);
-            if (t < NR) pend = load_piece(c + 1, t);
-        }
+        if (norm_a && c + 1 < nchunks && t == 0) stage_norm(c + 1);           // visible after the next barrier
         const int ty = (t * 21846) >> 16, tx = t - ty * 3;
         int a_ad[TM], b_ad[TN];
 #pragma unroll
@@ -226,6 +238,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const Conv
                 for (int j = 0; j < TN; ++j) bfr[nxt][j] = *(const f16x8*)(smem + (b_ad[j] ^ ((kk + 1) << 5)));
             }
             if (kk == 1 && halo_more) issue_a(c + 1, (c + 1) & 1, t);
+            // normalised halo: the VALU work of a piece sits in the middle of the step's MFMA stream (right after the step
+            // barrier every wave would do it at once and the matrix pipe would idle); the piece was loaded one step earlier
+            if (kk == 2 && norm_a && c + 1 < nchunks) {
+                if (t >= 1 && t <= NR) store_piece((c + 1) & 1, c + 1, t - 1, pend, pend_res);
+                if (t < NR) { pend = load_piece(c + 1, t); pend_res = load_res_piece(c + 1, t); }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -320,9 +338,10 @@ int gdt_launch_conv_halo(const ConvLaunch& d_in, hipStream_t stream) {
     }
     static const int small = [] { const char* e = getenv("GDT_HALO_SMALL"); return e ? atoi(e) : 0; }();   // experiment knob
     if (small == 1 && d.CoutPad % 128 == 0) return launch_halo<8, 128, 2, 2>(d, stream);  // two workgroups per CU
-    // 16 wavefronts (64x64 per wave, 4 per SIMD): equal to the 8-wave form on plain layers (0.281 vs 0.283 ms), faster when the
-    // InstanceNorm of the producer is applied while staging (0.299 vs 0.316 ms): more waves hide the register-staged halo path
-    if ((small == 2 || d.in_norm) && d.CoutPad % 256 == 0) return launch_halo<16, 256, 4, 4>(d, stream);
+    // 16 wavefronts (64x64 per wave, 4 per SIMD): equal to the 8-wave form on plain layers (0.281 vs 0.283 ms).  With the
+    // producer's InstanceNorm applied while staging it is the slower one (0.51 vs 0.32 ms) since the staging moved into the
+    // MFMA stream: at 128 registers per lane the extra live values spill.  Kept as an experiment knob.
+    if (small == 2 && d.CoutPad % 256 == 0) return launch_halo<16, 256, 4, 4>(d, stream);
     if (d.CoutPad % 256 == 0) return launch_halo<16, 256, 2, 4>(d, stream);
     if (d.CoutPad % 128 == 0) return launch_halo<16, 128, 4, 2>(d, stream);
     return launch_halo<16, 64, 8, 1>(d, stream);

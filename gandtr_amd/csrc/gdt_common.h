@@ -54,6 +54,8 @@ struct ConvLaunch {
     const f16* zeros;     // >= 16 B of zeros (source for padded / out-of-range chunks)
     const float* in_norm; // optional fused InstanceNorm of the INPUT: (mean, rstd) pairs [N][Cin][2], applied while staging A
     int in_relu;          // ... followed by ReLU
+    const f16* in_res;    // ... then + residual (ResnetBlock output y = x + IN(conv), p2p_networks.py:505), same layout as `in`
+    f16* in_out;          // ... and the transformed input is ALSO written here (each patch writes its interior pixels)
     int N, H, W, Cin, lc8;        // lc8 = log2(Cin / 8)
     int Cout, CoutPad, Kpad, nk;  // nk = Kpad / 64
     int OHg, OWg, OH, OW;         // output grid of this launch, full output size

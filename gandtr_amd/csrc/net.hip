@@ -215,9 +215,23 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     }
     for (int j = 0; j < nops && allow_norm_fusion; ++j) {
         const Op& oj = ops[j];
-        if (oj.kind != OP_INORM || oj.res >= 0 || consumers[oj.out] != 1 || net->precision) continue;   // f16x3: measured neutral
+        if (oj.kind != OP_INORM || net->precision) continue;          // f16x3: measured neutral
+        // plain norm(+ReLU): exactly one consumer.  norm + residual (ResnetBlock output): the tensor itself is still needed
+        // later (as the next block's residual), so the consuming conv also writes it out -- every other consumer must come
+        // after that conv in program order.
+        if (oj.res < 0 && consumers[oj.out] != 1) continue;
 
-        const int k = consumer_op[oj.out];
+        int k = consumer_op[oj.out];
+        if (oj.res >= 0) {
+            k = -1;
+            for (int i = j + 1; i < nops && k < 0; ++i) {
+                const Op& oi = ops[i];
+                bool uses = oi.in == oj.out || oi.res == oj.out;
+                if (oi.kind == OP_HED) for (int f = 0; f < 5; ++f) uses = uses || oi.feats[f] == oj.out;
+                if (uses) k = i;
+            }
+            if (k < 0) continue;
+        }
         const Op& ok = ops[k];
         if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || ok.cd.transposed) continue;
         if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
@@ -227,7 +241,8 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         d.w_lo = net->precision ? (const f16*)net : nullptr;                       // non-null marker only
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
         d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
-        const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d) : (gdt_conv_halo_eligible(d) || gdt_conv_igemm_norm_eligible(d));
+        const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d)
+                                         : (gdt_conv_halo_eligible(d) || (oj.res < 0 && gdt_conv_igemm_norm_eligible(d)));
         if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; }
     }
 
@@ -238,6 +253,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const int in = o.kind == OP_CONV ? conv_input(i) : o.in;
         if (in >= 0) T[in].last_use = i;
         if (o.res >= 0) T[o.res].last_use = i;
+        if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0 && ops[plan.steps[i].norm_from].res >= 0) {
+            const Op& nj = ops[plan.steps[i].norm_from];          // the conv reads the residual and writes the norm's output tensor
+            T[nj.res].last_use = std::max(T[nj.res].last_use, i);
+            T[nj.out].last_use = std::max(T[nj.out].last_use, i);
+        }
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = i;
     }
     Arena arena;
@@ -275,7 +295,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
                 const size_t mr_bytes = (size_t)N * ti.C * 2 * sizeof(float);
-                if (st.norm_into < 0) alloc_out();
+                if (st.norm_into < 0 || o.res >= 0) alloc_out();          // (folded + residual: the consuming conv writes it)
                 st.aux_off[1] = arena.alloc(mr_bytes);
                 if (o.stats_from >= 0 && slab_bytes[o.stats_from]) {
                     st.fused_stats = true;
@@ -316,6 +336,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         };
         maybe_free(o.kind == OP_CONV ? conv_input(i) : o.in); maybe_free(o.res);
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) maybe_free(o.feats[k]);
+        if (o.kind == OP_CONV && st.norm_from >= 0) { maybe_free(ops[st.norm_from].res); maybe_free(ops[st.norm_from].out); }
         if (o.out >= 0 && T[o.out].last_use == -1 && T[o.out].bytes) arena.release(T[o.out].off, T[o.out].bytes);   // never consumed
         for (auto& r : deferred[i]) arena.release(r.first, r.second);
     }
@@ -711,6 +732,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.in = tptr(nj.in);
                     d.in_norm = (const float*)(ws + plan.steps[stp.norm_from].aux_off[1]);
                     d.in_relu = nj.relu;
+                    if (nj.res >= 0) { d.in_res = tptr(nj.res); d.in_out = tptr(nj.out); }
                 }
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
