@@ -54,6 +54,7 @@ struct ConvLaunch {
     const f16* zeros;     // >= 16 B of zeros (source for padded / out-of-range chunks)
     const float* in_norm; // optional fused InstanceNorm of the INPUT: (mean, rstd) pairs [N][Cin][2], applied while staging A
     int in_relu;          // ... followed by ReLU
+    const f16* w_frag;    // weights in MFMA B-fragment order [CoutPad/32][Kpad/16][64 lanes][8] (3x3 s1 p1 layers, else null)
     const f16* in_res;    // ... then + residual (ResnetBlock output y = x + IN(conv), p2p_networks.py:505), same layout as `in`
     f16* in_out;          // ... and the transformed input is ALSO written here (each patch writes its interior pixels)
     int N, H, W, Cin, lc8;        // lc8 = log2(Cin / 8)
@@ -70,7 +71,7 @@ struct ConvLaunch {
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
 };
 
-// variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>
+// variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>
 // Workgroup -> (M tile, N tile).  Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md), each
 // with a private L2.  Every XCD therefore gets ONE contiguous span of M tiles: spatially adjacent tiles (which share input
 // rows through the kernel taps / halos) and the N tiles of one M tile (which share the whole A operand) meet in the same L2.
@@ -90,6 +91,8 @@ int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = null
 bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d);    // conv_igemm.hip: fused input InstanceNorm in the generic kernel
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip (weights streamed into registers)
+int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32
 int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
 bool gdt_conv_halo_x3_eligible(const ConvLaunch& d);       // conv3x3_halo_x3.hip

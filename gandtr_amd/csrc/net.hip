@@ -30,6 +30,7 @@ enum OpKind { OP_INPUT, OP_CONV, OP_INORM, OP_MAXPOOL, OP_GEM, OP_OUT_NCHW, OP_H
 struct PackedPhase {
     size_t w_off = 0;                 // byte offset in the device weight blob
     size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
+    size_t w_frag_off = 0; bool has_frag = false;   // fp16 mode, 3x3 s1 p1: copy in MFMA B-fragment order (conv3x3_halo_rb.hip)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
 };
@@ -461,6 +462,20 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 }
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
         if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
+        if (!net->precision && !cd.transposed && cd.kh == 3 && cd.kw == 3 && cd.stride == 1 && cd.pad == 1 && cin_pad % 64 == 0 &&
+            o.cout_pad % 256 == 0) {
+            // fragment order: lane = fh * 32 + fr holds cout = cb * 32 + fr, k = ks * 16 + fh * 8 + e
+            const int nks = ph.Kpad / 16;
+            std::vector<f16> pf(pk.size());
+            for (int cb = 0; cb < o.cout_pad / 32; ++cb)
+                for (int ks = 0; ks < nks; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const f16* src = pk.data() + (size_t)(cb * 32 + (ln & 31)) * ph.Kpad + ks * 16 + (ln >> 5) * 8;
+                        std::copy(src, src + 8, pf.data() + (((size_t)cb * nks + ks) * 64 + ln) * 8);
+                    }
+            ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
+            ph.has_frag = true;
+        }
     };
 
     if (o.rowsplit) {
@@ -746,6 +761,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     else { d.out = tptr(o.out); d.out_f32 = nullptr; }
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
                     d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
+                    d.w_frag = ph.has_frag ? (const f16*)(net->dev_blob + ph.w_frag_off) : nullptr;
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;

@@ -14,3 +14,11 @@ net.finalize()
 x = synth.synth_input(1, (64, 3, 64, 64)).to(dev)
 for _ in range(5): net.forward(x)
 torch.cuda.synchronize()
+net.set_profiling(True)
+acc = None
+for _ in range(10):
+    net.forward(x)
+    p = net.profile()
+    ms = [r[2] for r in p]
+    acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
+print("per-op ms:", " ".join("%s:%.3f" % (p[i][0], acc[i] / 10) for i in range(len(p))))
