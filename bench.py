@@ -52,6 +52,8 @@ def timed(fn, steps, warmup, dev, distributed):
 def kernel_name(variant):
     if variant >= 930000:
         return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
+    if variant >= 920000:
+        return "conv_head7_kernel"
     if variant >= 910000:
         return "conv3x3_halo_rb_kernel<%d>" % (variant - 910000)
     if variant >= 900000:

@@ -144,27 +144,37 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
 
 // stage 2 (fused-statistics variant): the partials were written by the conv epilogue, one [2][C] record per 128-row tile;
 // tile index = phase * (N * tpi) + n * tpi + t   (phases: 1 for Conv2d, 4 for the ConvTranspose2d sub-pixel launches)
-__global__ __launch_bounds__(256) void in_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
-                                                                int tpi, int nphase, int N, int C, int HW, float eps) {
-    // grid (C / 64, N): 64 channels x 4 record lanes per workgroup; records are strided over the 4 lanes and merged in a
-    // fixed order (fp64), so the result does not depend on scheduling
-    __shared__ double red[2][4][64];
+__global__ __launch_bounds__(1024) void in_finalize_tiles_kernel(const float* __restrict__ partial, float* __restrict__ mean_rstd,
+                                                                 int tpi, int nphase, int N, int C, int HW, float eps) {
+    // grid (C / 64, N): 64 channels x 16 record lanes per workgroup; records are strided over the lanes, four independent
+    // loads in flight per lane (one at a time, a 256x256 layer's 512 records per image took 69 us of pure load latency), and
+    // everything is merged in a fixed order (fp64), so the result does not depend on scheduling
+    constexpr int RL = 16;
+    __shared__ double red[2][RL][64];
     const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lanegrp = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
     if (c < C) {
         const int nrec = nphase * tpi;
-        for (int r = lanegrp; r < nrec; r += 4) {
-            const int ph = r / tpi, t = r - ph * tpi;
-            const long tile = (long)ph * N * tpi + (long)n * tpi + t;
-            s += (double)partial[(tile * 2 + 0) * C + c];
-            q += (double)partial[(tile * 2 + 1) * C + c];
+        auto rec = [&](int r, float& a, float& b) {
+            if (r < nrec) {
+                const int ph = r / tpi, t = r - ph * tpi;
+                const long tile = (long)ph * N * tpi + (long)n * tpi + t;
+                a = partial[(tile * 2 + 0) * C + c]; b = partial[(tile * 2 + 1) * C + c];
+            } else { a = 0.f; b = 0.f; }
+        };
+        for (int r = lanegrp; r < nrec; r += 4 * RL) {
+            float a0, b0, a1, b1, a2, b2, a3, b3;
+            rec(r, a0, b0); rec(r + RL, a1, b1); rec(r + 2 * RL, a2, b2); rec(r + 3 * RL, a3, b3);
+            s += (double)a0; q += (double)b0; s += (double)a1; q += (double)b1;
+            s += (double)a2; q += (double)b2; s += (double)a3; q += (double)b3;
         }
     }
     red[0][lanegrp][threadIdx.x & 63] = s; red[1][lanegrp][threadIdx.x & 63] = q;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
-        s = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
-        q = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int l = 0; l < RL; ++l) { s += red[0][l][threadIdx.x]; q += red[1][l][threadIdx.x]; }
         const double m = s / HW;
         double var = q / HW - m * m;
         var = var < 0.0 ? 0.0 : var;
@@ -464,7 +474,7 @@ int gdt_k_instance_norm(const void* x, const void* res, void* y, int f32, float*
 
 int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, const float* tile_partials, int tiles_per_image,
                               int nphase, float* mean_rstd, int N, int HW, int C, float eps, int relu, hipStream_t st) {
-    hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, tile_partials, mean_rstd,
+    hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(1024), 0, st, tile_partials, mean_rstd,
                        tiles_per_image, nphase, N, C, HW, eps);
     GDT_CHECK_HIP(hipGetLastError());
     return launch_apply(x, res, y, f32, mean_rstd, N, HW, C, relu, st);
@@ -474,7 +484,7 @@ int gdt_k_instance_norm_fused(const void* x, const void* res, void* y, int f32, 
 int gdt_k_instance_norm_stats(const void* x, int f32, int fused, float* partial, int tiles_per_image, int nphase, float* mean_rstd,
                               int N, int HW, int C, float eps, hipStream_t st) {
     if (fused) {
-        hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(256), 0, st, (const float*)partial, mean_rstd,
+        hipLaunchKernelGGL(in_finalize_tiles_kernel, dim3((C + 63) / 64, N), dim3(1024), 0, st, (const float*)partial, mean_rstd,
                            tiles_per_image, nphase, N, C, HW, eps);
         GDT_CHECK_HIP(hipGetLastError());
         return GDT_OK;

@@ -70,11 +70,12 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 // straight across tile boundaries: the first halo chunk and the first weight slice of the NEXT tile are fetched during the
 // last chunk of the current one, and the epilogue's global stores drain while the next tile's MFMAs run (with one workgroup
 // per tile every CU reached its epilogue at the same moment: 33 MB of stores in one burst, ~13k idle cycles per tile).
-// MODE 0: plain input (halo by LDS-DMA); 1: producer's InstanceNorm (+ReLU) applied while staging; 2: ... + residual, and
-// the transformed tensor written back (ResnetBlock output folded into the next block's first conv).
+// MODE bits: 1 = the producer's InstanceNorm (+ReLU) is applied while staging; 2 = ... plus a residual; 4 = the transformed
+// tensor is written back (it has further consumers).  Built: 0, 1, 5 (norm + write-back), 7 (norm + residual + write-back:
+// the ResnetBlock output folded into the next block's first conv).
 template <int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
-    constexpr bool NORM = MODE != 0, RES = MODE == 2;
+    constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
     constexpr int NR = (HALO_ROWS_PAD + RPR - 1) / RPR;
     static_assert(NR <= 7, "halo rounds are spread over the taps of the previous chunk");
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             o = p.ok ? p.raw : z;
         } else {
             const int cq = (p.goff >> 3) & ((1 << d.lc8) - 1);                     // chunk * 8 + q
-            // (MODE 2 needs the true value of the clamped pixel for the write-back and zeroes the LDS copy afterwards)
-            const float4* np4 = (const float4*)(nlds + ((RES || p.ok) ? slot * 512 + cq * 16 : ZERO_ENTRY));
+            // (write-back needs the true value of the clamped pixel for the write-back and zeroes the LDS copy afterwards)
+            const float4* np4 = (const float4*)(nlds + ((WB || p.ok) ? slot * 512 + cq * 16 : ZERO_ENTRY));
             const float lo = d.in_relu ? 0.f : -3.0e38f;
             const u32x4 rawu = __builtin_bit_cast(u32x4, p.raw), resu = __builtin_bit_cast(u32x4, p.res);
             u32x4 ou;
@@ -170,10 +171,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                 o = __builtin_elementwise_max(o, lo8);
             }
         }
-        // The transformed tensor is materialised as a side effect (MODE 2).  EVERY piece stores the value of its (clamped,
+        // The transformed tensor is materialised as a side effect (MODE bit 4).  EVERY piece stores the value of its (clamped,
         // reflected) source pixel, halo pieces included: neighbouring patches write identical bits to the same place, which
         // is cheaper than a conditional store (27 % more store traffic, no branch in the loop).
-        if (RES) {
+        if (WB) {
             *(f16x8*)(d.in_out + p.goff) = o;
             o = p.ok ? o : z;
         }
@@ -418,5 +419,6 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
     d.dbg = dbg;
     if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
-    return d.in_res ? launch_rb<256, 2, 4, 2>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
+    if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
+    return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
 }

@@ -1,0 +1,227 @@
+// Generator head: 7x7 / stride-1 / pad-3 convolution from 64 channels to <= 4 image channels with tanh, fp32 NCHW output
+// (p2p_networks.py:433-436: ReflectionPad2d(3), Conv2d(ngf, output_nc, 7), Tanh) -- one fused, persistent kernel.
+//
+// A 64 -> 3 channel conv wastes the 32-wide MFMA N dimension; the row-split form fixes that: the GEMM runs over the 7 kernel
+// ROWS only (K = 7 * 64) and produces, per pixel, the 7 * cout partial sums P[kx * cout + co] (N = 21 -> 32), and the output
+// is the sum of 7 horizontally shifted partials.  The first implementation did this with the generic implicit GEMM plus a
+// combine kernel: every input row went L2 -> LDS seven times (once per kernel row) and the [pixels][24] fp16 partials made a
+// round trip through HBM -- 0.87 ms for 79 GFLOP, the slowest layer of the generator.  Here:
+//   * one workgroup computes an 8 x 32 output tile: the 14 x 38 input halo is staged ONCE in LDS (LDS-DMA, reflect padding
+//     resolved in the source address) and, when the preceding InstanceNorm + ReLU is folded in, normalised in place;
+//   * 4 wavefronts share the ten 32-row blocks of the 8 x 38 partial-sum image (the partials are needed 3 columns past the
+//     tile on either side): 28 v_mfma_f32_32x32x16_f16 per block with the whole weight matrix resident in registers (28 B
+//     fragments, loaded once: the kernel is persistent);
+//   * the fp32 partials go to LDS (over the consumed halo), and the combine (7 taps, + bias, tanh) writes fp32 NCHW rows of
+//     32 pixels.  Nothing but the input and the image touches HBM (537 MB + 50 MB per 64 x 256^2 batch);
+//   * 70 KB of LDS and 4 waves: two workgroups per CU, so one loads / normalises / combines while the other runs its MFMAs
+//     (a single double-buffered workgroup measured 0.46 ms with its phases serialised by barriers).
+#include <cstdio>
+#include <cstdlib>
+
+#include "gdt_common.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int PH = 8, PW = 32, KT = 7;
+constexpr int HWD = PW + KT - 1;                 // 38 halo columns
+constexpr int HHT = PH + KT - 1;                 // 14 halo rows
+constexpr int HPIX = HHT * HWD;                  // 532 halo pixels of 128 B
+constexpr int NWAVE = 4, NT = NWAVE * 64, NBLK = 10;        // ten 32-row blocks of partial-sum pixels over four waves
+constexpr int MROWS = PH * HWD;                  // 304 partial-sum pixels
+constexpr int LOAD_ROWS8 = (HPIX + 7) / 8;       // 67 wave-wide 1 KB loads per tile
+constexpr int LROWS = 552;                       // LDS rows of the halo buffer: >= NBLK * 32 - 1 + 6 * HWD + 1 = 548
+constexpr int HBYTES = LROWS * 128;              // 70,656 B: two workgroups per CU
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PSTRIDE = 33;                      // floats per partial-sum pixel (odd: the 7-tap combine is conflict free)
+static_assert(NBLK * 32 >= MROWS && NBLK * 32 * PSTRIDE * 4 <= HBYTES && LROWS >= LOAD_ROWS8 * 8 && NBLK <= 3 * NWAVE, "layout");
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
+}
+// LDS-only workgroup barrier (no global-memory fence: global stores / loads stay in flight across it)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tiles_x = (d.W + PW - 1) / PW, tiles_y = (d.H + PH - 1) / PH, tpi = tiles_x * tiles_y;
+    const int cout = d.Cout;
+
+    // XCD-chunked persistent schedule: workgroup b (XCD b & 7, slot b >> 3) walks the tiles slot, slot + S, ... of its XCD's
+    // contiguous span, so the CUs of one XCD hold neighbouring tiles (shared halo rows hit its L2) at any time
+    const int per_xcd = (ntiles + 7) >> 3, S = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int span_lo = xcd * per_xcd, span_hi = min(span_lo + per_xcd, ntiles);
+    int tile = span_lo + slot;
+    if (tile >= span_hi) return;
+
+    // Blocks of 32 partial-sum pixels per wave: 10 blocks over 4 waves is 3,3,2,2.  The two workgroups that share a CU sit
+    // on the same four SIMDs; rotating the assignment by two waves in every other workgroup makes it 5,5,5,5 per SIMD.
+    const int wrot = (wave + 2 * (int)(blockIdx.x >= gridDim.x / 2)) & 3;     // (workgroups b and b + grid/2 share a CU)
+    const int nb = wrot < NBLK - 2 * NWAVE ? 3 : 2;         // blocks wrot, wrot + 4 (, wrot + 8)
+
+    // the whole B operand lives in registers: fragment ks holds k = ks * 16 + fh * 8 .. +8 of output column fr
+    f16x8 bw[4 * KT];
+#pragma unroll
+    for (int ks = 0; ks < 4 * KT; ++ks) bw[ks] = *(const f16x8*)(d.w_frag + ((long)ks * 64 + lane) * 8);
+
+    const bool refl = d.pad_reflect != 0;
+    // A fragment of partial-sum pixel m = block * 32 + fr for kernel row ky: halo pixel m + ky * 38.  The swizzle term
+    // depends on the row modulo 16 only, and a block shifts the row by a multiple of 32: one address set serves every block.
+    int a_base[KT];
+#pragma unroll
+    for (int ky = 0; ky < KT; ++ky) {
+        const int row = wrot * 32 + fr + ky * HWD;
+        a_base[ky] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+    }
+    // (scale, shift) of the folded InstanceNorm for 16-byte channel group tid & 7 of the current image
+    const int c8 = tid & 7;
+
+    for (;;) {
+        const int n = tile / tpi, r = tile - n * tpi;
+        const int y0 = (r / tiles_x) * PH, x0 = (r % tiles_x) * PW;
+        float4 nv[4];                                    // (mean, rstd) x 2 channels, x 4: loaded BEFORE the DMA is issued, so
+        if (d.in_norm) {                                 // that waiting for them does not wait for the halo
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nv[k] = *(const float4*)(d.in_norm + ((long)n * 64 + c8 * 8) * 2 + k * 4);
+        }
+        // ---- halo: 67 wave-wide 1 KB DMA rounds (reflect / zero padding resolved in the source address)
+        if (!(d.dbg & 8) || tile == span_lo + slot) {
+#pragma unroll 1
+            for (int j = 0; j < (LOAD_ROWS8 + NWAVE - 1) / NWAVE; ++j) {
+                const int row8 = min(wave + j * NWAVE, LOAD_ROWS8 - 1);     // (the surplus round repeats the last one)
+                const int hp = row8 * 8 + (lane >> 3);
+                const int hy = (hp * 1725) >> 16, hx = hp - hy * HWD;       // hp / 38 for hp < 2^11
+                const int iy = y0 - 3 + hy, ix = x0 - 3 + hx;
+                int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+                int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+                ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
+                const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+                const bool ok = (hp < HPIX) & (inb | refl);
+                const int q = (lane & 7) ^ ((hp >> 1) & 7);                   // XOR swizzle on the 16-byte chunk (as conv_igemm.hip)
+                const f16* src = d.in + ((long)((n * d.H + ry) * d.W + rx) * 64 + q * 8);
+                glds16(ok ? src : d.zeros, smem + row8 * 1024);
+            }
+        }
+        __syncthreads();                               // DMA landed (the barrier drains vmcnt) and visible
+
+        if (d.in_norm && !(d.dbg & 1)) {
+            // The producer's InstanceNorm + ReLU (p2p_networks.py:429-431, the up-sampling block before the head) applied in
+            // place to the staged halo.  Thread t always handles 16-byte channel group t & 7 (its eight (scale, shift) pairs
+            // are fetched once per tile); pieces of padding pixels stay zero.
+            const unsigned lo2 = d.in_relu ? 0u : 0xfbfffbffu;                   // packed fp16 floor: 0 or -65504
+            float sc[8], sh[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[2 * k] = nv[k].y; sh[2 * k] = -nv[k].x * nv[k].y; sc[2 * k + 1] = nv[k].w; sh[2 * k + 1] = -nv[k].z * nv[k].w; }
+            int t8 = tid >> 3;
+            asm volatile("" : "+v"(t8));             // (keeps the per-round pixel arithmetic inside the tile loop: hoisted, it spills)
+#pragma unroll 2
+            for (int j = 0; j < (HPIX + NT / 8 - 1) / (NT / 8); ++j) {
+                const int hp = t8 + j * (NT / 8);
+                const int hy = (hp * 1725) >> 16, hx = hp - hy * HWD;
+                const int iy = y0 - 3 + hy, ix = x0 - 3 + hx;
+                const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+                const bool ok = (hp < HPIX) & (inb | refl);
+                char* pp = smem + min(hp, LROWS - 1) * 128 + ((c8 ^ ((hp >> 1) & 7)) << 4);
+                const u32x4 raw = *(const u32x4*)pp;
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned w;
+                    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(w) : "v"(raw[k]), "v"(sc[2 * k]), "v"(sh[2 * k]));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(w) : "v"(raw[k]), "v"(sc[2 * k + 1]), "v"(sh[2 * k + 1]));
+                    asm("v_pk_max_f16 %0, %1, %2" : "=v"(w) : "v"(w), "v"(lo2));
+                    o[k] = ok ? w : 0u;
+                }
+                if (hp < LROWS) *(u32x4*)pp = o;
+            }
+            lds_barrier();
+        }
+
+        // ---- GEMM over the kernel rows: 2 or 3 independent accumulator chains per wave
+        f32x16 acc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        if (!(d.dbg & 2)) {
+            constexpr int PF = 3;                                  // fragment sets in flight (LDS latency vs 3 MFMAs per set)
+            f16x8 afr[PF][3];
+            auto frags = [&](int ks, f16x8 (&f)[3]) {
+                const int off = a_base[ks >> 2] ^ ((ks & 3) << 5);
+                f[0] = *(const f16x8*)(smem + off);
+                f[1] = *(const f16x8*)(smem + off + NWAVE * 32 * 128);
+                if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
+            };
+#pragma unroll
+            for (int p = 0; p < PF - 1; ++p) frags(p, afr[p]);
+#pragma unroll
+            for (int ks = 0; ks < 4 * KT; ++ks) {
+                if (ks + PF - 1 < 4 * KT) frags(ks + PF - 1, afr[(ks + PF - 1) % PF]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], bw[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], bw[ks], acc[1], 0, 0, 0);
+                if (nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], bw[ks], acc[2], 0, 0, 0);
+            }
+        }
+        lds_barrier();                                 // the halo has been consumed by every wave
+        float* P = (float*)smem;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (b < nb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) P[((wrot + b * NWAVE) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * PSTRIDE + fr] = acc[b][e];
+            }
+        lds_barrier();
+        for (int idx = tid; idx < cout * PH * PW && !(d.dbg & 4); idx += NT) {
+            const int co = idx >> 8, y = (idx >> 5) & 7, x = idx & 31;
+            float v = d.bias ? d.bias[co] : 0.f;
+#pragma unroll
+            for (int kx = 0; kx < KT; ++kx) v += P[(y * HWD + x + kx) * PSTRIDE + kx * cout + co];
+            if (d.act == 1) v = tanhf(v);
+            else if (d.act == 2) v = 1.f / (1.f + __expf(-v));
+            if (y0 + y < d.H && x0 + x < d.W) d.out_f32[(((long)n * cout + co) * d.H + y0 + y) * d.W + x0 + x] = v;
+        }
+        tile += S;
+        if (tile >= span_hi) break;
+        lds_barrier();                                 // the partial sums have been read: the buffer may be refilled
+    }
+}
+
+}  // namespace
+
+// 7x7 stride-1 pad-3 conv, 64 input channels, <= 4 output channels, fp32 NCHW output, fragment-ordered row-split weights
+bool gdt_conv_head7_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HEAD7"); return e ? atoi(e) : 1; }();
+    return mode != 0 && d.w_frag && d.out_f32 && d.Cin == 64 && d.Cout >= 1 && d.Cout <= 4 && d.ntaps == KT &&
+           (long)d.N * d.H * d.W * 64 < (1L << 31);
+}
+
+int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
+    static int cus = 0;
+    constexpr int lds = HBYTES;
+    if (!cus) {
+        int dev = 0;
+        GDT_CHECK_HIP(hipGetDevice(&dev));
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus / 8 * 8;
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
+    static const int wgs = [] { const char* e = getenv("GDT_HEAD7_WGS"); return e ? atoi(e) : 2; }();
+    const int grid = min(wgs * cus, (ntiles + 7) / 8 * 8);     // two workgroups per CU: one loads while the other computes
+    static const int dbg = [] { const char* e = getenv("GDT_HEAD7_DBG"); return e ? atoi(e) : 0; }();
+    ConvLaunch dd = d;
+    dd.dbg = dbg;
+    hipLaunchKernelGGL(conv_head7_kernel, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}

@@ -137,6 +137,7 @@ struct Step {
     int op; size_t aux_off[8]; bool fused_stats; int tiles_per_image;
     int norm_into;   // INORM: index of the conv op that applies this normalisation while staging its input (-1: own apply pass)
     int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
+    bool wb;         // INORM folded into a conv that also writes the normalised tensor out (residual / further consumers)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
 
@@ -220,10 +221,9 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         // plain norm(+ReLU): exactly one consumer.  norm + residual (ResnetBlock output): the tensor itself is still needed
         // later (as the next block's residual), so the consuming conv also writes it out -- every other consumer must come
         // after that conv in program order.
-        if (oj.res < 0 && consumers[oj.out] != 1) continue;
-
+        const bool wb = oj.res >= 0 || consumers[oj.out] != 1;       // the normalised tensor itself must exist afterwards
         int k = consumer_op[oj.out];
-        if (oj.res >= 0) {
+        if (wb) {
             k = -1;
             for (int i = j + 1; i < nops && k < 0; ++i) {
                 const Op& oi = ops[i];
@@ -243,8 +243,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
         d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
         const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d)
-                                         : (gdt_conv_halo_eligible(d) || (oj.res < 0 && gdt_conv_igemm_norm_eligible(d)));
-        if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; }
+                                         : (gdt_conv_halo_eligible(d) || (!wb && gdt_conv_igemm_norm_eligible(d)));
+        if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
+        static const bool plan_dbg = getenv("GDT_PLAN_DEBUG") != nullptr;
+        if (plan_dbg) fprintf(stderr, "[plan] inorm %d -> conv %d: Cin %d s%d k%d rowsplit %d fold %d\n", j, k, d.Cin, ok.cd.stride, ok.cd.kh, (int)ok.rowsplit, (int)fold);
     }
 
     // ---- pass 3: liveness + first-fit layout
@@ -254,9 +256,9 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const int in = o.kind == OP_CONV ? conv_input(i) : o.in;
         if (in >= 0) T[in].last_use = i;
         if (o.res >= 0) T[o.res].last_use = i;
-        if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0 && ops[plan.steps[i].norm_from].res >= 0) {
+        if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0 && plan.steps[plan.steps[i].norm_from].wb) {
             const Op& nj = ops[plan.steps[i].norm_from];          // the conv reads the residual and writes the norm's output tensor
-            T[nj.res].last_use = std::max(T[nj.res].last_use, i);
+            if (nj.res >= 0) T[nj.res].last_use = std::max(T[nj.res].last_use, i);
             T[nj.out].last_use = std::max(T[nj.out].last_use, i);
         }
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = i;
@@ -296,7 +298,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             case OP_INORM: {
                 const Tensor& ti = T[o.in];
                 const size_t mr_bytes = (size_t)N * ti.C * 2 * sizeof(float);
-                if (st.norm_into < 0 || o.res >= 0) alloc_out();          // (folded + residual: the consuming conv writes it)
+                if (st.norm_into < 0 || st.wb) alloc_out();               // (folded with write-back: the consuming conv writes it)
                 st.aux_off[1] = arena.alloc(mr_bytes);
                 if (o.stats_from >= 0 && slab_bytes[o.stats_from]) {
                     st.fused_stats = true;
@@ -498,6 +500,18 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                         }
             ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
             if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
+            if (!net->precision && cin_pad == 64 && cd.kh == 7 && cd.kw == 7 && o.cout_pad == 32) {
+                // conv_head7.hip keeps the whole matrix in registers: B fragment ks of lane (fh, fr) = column fr, k = ks*16 + fh*8 ..
+                const int nks = ph.Kpad / 16;
+                std::vector<f16> pf((size_t)nks * 64 * 8);
+                for (int ks = 0; ks < nks; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const f16* src = pk.data() + (size_t)(ln & 31) * ph.Kpad + ks * 16 + (ln >> 5) * 8;
+                        std::copy(src, src + 8, pf.data() + ((size_t)ks * 64 + ln) * 8);
+                    }
+                ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
+                ph.has_frag = true;
+            }
         }
         o.phases.push_back(ph);
     } else if (!cd.transposed) {
@@ -747,12 +761,13 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.in = tptr(nj.in);
                     d.in_norm = (const float*)(ws + plan.steps[stp.norm_from].aux_off[1]);
                     d.in_relu = nj.relu;
-                    if (nj.res >= 0) { d.in_res = tptr(nj.res); d.in_out = tptr(nj.out); }
+                    if (plan.steps[stp.norm_from].wb) { d.in_res = nj.res >= 0 ? tptr(nj.res) : nullptr; d.in_out = tptr(nj.out); }
                 }
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
                 d.stats = stp.fused_stats ? (float*)(ws + stp.aux_off[0]) : nullptr;
                 int phase_idx = 0;
+                bool fused_head = false;
                 for (const PackedPhase& ph : o.phases) {
                     conv_geometry(net, o, ph, n, ti, d);
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
@@ -765,11 +780,22 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
+                    if (o.rowsplit && !f32) {           // fused head kernel: GEMM over the kernel rows + combine + activation in one launch
+                        ConvLaunch h = d;
+                        h.out = nullptr; h.out_f32 = (float*)outputs[o.slot]; h.Cout = o.cd.cout; h.act = o.cd.act;
+                        h.bias = o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr;
+                        if (gdt_conv_head7_eligible(h)) {
+                            rc = gdt_launch_conv_head7(h, st);
+                            if (net->profiling) net->last_variant[stp.op] = 920007;
+                            fused_head = true;
+                            break;
+                        }
+                    }
                     rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;
                 }
-                if (o.rowsplit && rc == GDT_OK)
+                if (o.rowsplit && !fused_head && rc == GDT_OK)
                     rc = gdt_k_rowsplit_combine(d.out, f32, o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr,
                                                 (float*)outputs[o.slot], n, d.OH, ti.W, o.rs_cout8, o.cd.cout, o.cd.kw, o.cd.pad,
                                                 o.cd.pad_reflect, o.cd.act, st);

@@ -84,6 +84,60 @@ def test_conv_ragged_tail(cuda_device):
     assert _rel(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 37, 53), (1, 8, 32)])
+def test_generator_head_7x7_tanh(cuda_device, norm, shape):
+    """ReflectionPad2d(3) + Conv2d(64, 3, 7) + Tanh (p2p_networks.py:433-436), fp32 NCHW output: the fused head kernel
+    (conv_head7.hip), alone and with the preceding InstanceNorm + ReLU folded into its input staging; ragged tiles."""
+    from gandtr_amd.engine import HipNet
+    n, h, w = shape
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    t = net.conv(t, synth._normal(0, "w0", (64, 3, 3, 3), 0.4), pad=1, reflect=True)
+    tap_in = net.output_nchw(t)
+    u = net.instance_norm(t, relu=True) if norm else t
+    wt, b = synth._normal(0, "wh", (3, 64, 7, 7), 0.03), synth._normal(0, "bh", (3,), 0.2)
+    o = net.conv(u, wt, b, pad=3, reflect=True, act=1, out_f32=True)          # act 1 = tanh; returns the output slot
+    net.finalize()
+    x = synth.synth_input(2, (n, 3, h, w))
+    outs = net.forward(x.to(cuda_device))
+    xin = outs[tap_in].cpu()
+    if norm:
+        xin = F.relu(F.instance_norm(xin, eps=1e-5)).half().float()      # the head consumes fp16-rounded activations
+    ref = torch.tanh(F.conv2d(F.pad(xin, (3,) * 4, mode="reflect"), wt.half().float(), b))
+    got = outs[o].cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < (3e-3 if norm else 1.5e-3)
+
+
+def test_resnet_block_chain_folds(cuda_device):
+    """Three ResnetBlocks (p2p_networks.py:480-505) at 256 channels behind an InstanceNorm whose output feeds both the first
+    conv and the first residual: exercises the folded norm with write-back (norm only, and norm + residual) of
+    conv3x3_halo_rb.hip and the plain apply pass for the final block output."""
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    raw = net.conv(t, synth._normal(0, "w0", (256, 3, 3, 3), 0.3), pad=1, reflect=True)
+    tap = net.output_nchw(raw)
+    y = net.instance_norm(raw, relu=True)
+    ws = []
+    for i in range(3):
+        w1, w2 = synth._normal(0, "a%d" % i, (256, 256, 3, 3), 0.03), synth._normal(0, "b%d" % i, (256, 256, 3, 3), 0.03)
+        ws.append((w1, w2))
+        u = net.instance_norm(net.conv(y, w1, pad=1, reflect=True), relu=True)
+        y = net.instance_norm(net.conv(u, w2, pad=1, reflect=True), relu=False, residual=y)
+    out = net.output_nchw(y)
+    net.finalize()
+    x = synth.synth_input(5, (16, 3, 32, 32))          # 16 images x 4 patches: enough tiles for the LDS-resident kernels
+    outs = net.forward(x.to(cuda_device))
+    r = F.relu(F.instance_norm(outs[tap].cpu(), eps=1e-5))
+    q = lambda v: v.half().float()
+    for w1, w2 in ws:
+        u = F.relu(F.instance_norm(F.conv2d(F.pad(q(r), (1,) * 4, mode="reflect"), q(w1)), eps=1e-5))
+        r = r + F.instance_norm(F.conv2d(F.pad(q(u), (1,) * 4, mode="reflect"), q(w2)), eps=1e-5)
+    assert _rel(outs[out].cpu(), r) < 4e-3
+
+
 def test_instance_norm_relu_residual(cuda_device):
     from gandtr_amd.engine import HipNet
     net = HipNet(cuda_device)
