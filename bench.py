@@ -50,6 +50,8 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 940000:
+        return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
     if variant >= 930000:
         return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
     if variant >= 920000:

@@ -206,6 +206,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         }
     }
 
+    auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
     static const bool allow_norm_fusion = [] { const char* e = getenv("GDT_NORM_FUSION"); return !e || atoi(e) != 0; }();
     std::vector<int> consumers(T.size(), 0), consumer_op(T.size(), -1);
@@ -240,10 +241,12 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
         if (ok.rowsplit) { d.Cout = ok.rs_cout8; d.out_f32 = nullptr; }
         d.w_lo = net->precision ? (const f16*)net : nullptr;                       // non-null marker only
+        d.w_frag = ok.phases[0].has_frag ? (const f16*)net : nullptr;              // non-null marker only
+        d.out = (ok.cd.out_f32_nchw || ok.rowsplit) ? nullptr : (f16*)net;         // non-null marker only
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
         d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
         const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d)
-                                         : (gdt_conv_halo_eligible(d) || (!wb && gdt_conv_igemm_norm_eligible(d)));
+                                         : (gdt_conv_halo_eligible(d) || (!wb && (gdt_conv_igemm_norm_eligible(d) || irb_norm_ok(d))));
         if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
         static const bool plan_dbg = getenv("GDT_PLAN_DEBUG") != nullptr;
         if (plan_dbg) fprintf(stderr, "[plan] inorm %d -> conv %d: Cin %d s%d k%d rowsplit %d fold %d\n", j, k, d.Cin, ok.cd.stride, ok.cd.kh, (int)ok.rowsplit, (int)fold);
@@ -464,8 +467,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 }
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
         if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
-        if (!net->precision && !cd.transposed && cd.kh == 3 && cd.kw == 3 && cd.stride == 1 && cd.pad == 1 && cin_pad % 64 == 0 &&
-            o.cout_pad % 256 == 0) {
+        if (!net->precision && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip
             // fragment order: lane = fh * 32 + fr holds cout = cb * 32 + fr, k = ks * 16 + fh * 8 + e
             const int nks = ph.Kpad / 16;
             std::vector<f16> pf(pk.size());
