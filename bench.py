@@ -50,6 +50,8 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 950000:
+        return "conv_stem_kernel<%d taps>" % (variant - 950000)
     if variant >= 940000:
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
     if variant >= 930000:

@@ -1,0 +1,220 @@
+// First layer of every network on the path: KxK convolution from an image (3 channels, padded to 8) to 64 channels
+//   generator stem  ReflectionPad2d(3) + Conv2d(3, 64, 7) (+ InstanceNorm statistics)         p2p_networks.py:269-272
+//   ResNet-101 stem Conv2d(3, 64, 7, stride 2, pad 3) + BN + ReLU                             torchvision resnet.py, sliced at
+//   VGG16 conv1_1   Conv2d(3, 64, 3, pad 1) + ReLU                                            imageretrievalnet.py:185-190
+// (gfx950, MI355X).  The generic implicit GEMM gathers this layer's A operand 16 bytes at a time (every 8-channel piece is
+// its own tap) and re-reads each input pixel K*K times from L2: 0.50 ms for the 79 GFLOP generator stem, 0.97 ms for the
+// ResNet stem, against ~0.12 ms of output traffic.  Here a pixel is ONE 16-byte LDS word:
+//   * a workgroup owns TH x 32 output pixels (TH = 4 rows per wave x 4 waves at stride 1, 2 x 4 at stride 2); the input halo
+//     ((TH-1)*S + K) x (31*S + K) pixels, 13-23 KB) is staged once by LDS-DMA, padding resolved in the source address;
+//   * K index = tap * 8 + channel, so one MFMA k-step (16) is two taps: the A fragment of lane (pixel fr, half fh) is the
+//     16-byte word of pixel (oy*S + ty, ox*S + tx) with tap = 2*ks + fh -- a plain ds_read_b128 at a per-lane base plus a
+//     compile-time offset (two bases: the second tap of a pair is either the next pixel or the start of the next halo row);
+//   * the weights (64 x K*K*8, up to 50 KB) sit in LDS in B-fragment order for the lifetime of the persistent workgroup;
+//   * MFMA operands swapped (D = W * A^T) so a lane holds 4 consecutive output channels: the epilogue transposes 32-pixel
+//     blocks through a wave-private LDS patch with 8-byte writes and stores whole 4 KB row segments; InstanceNorm
+//     statistics (one 128-pixel record per wave) come from the stored fp16 values, reduced in a fixed order.
+// Two workgroups share a CU (one loads while the other computes).
+#include <cstdio>
+#include <cstdlib>
+
+#include "gdt_common.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int TW = 32;                     // output tile width (one 32-pixel MFMA block per output row)
+constexpr int NWAVE = 4, NT = NWAVE * 64;
+constexpr int CP = 72;                     // halves per pixel row of the wave-private transpose patch (64 + 8)
+constexpr int PATCH_BYTES = 32 * CP * 2;   // 4608 B per wave
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
+}
+
+template <int KS, int S>
+struct StemCfg {
+    static constexpr int RPW = S == 1 ? 4 : 2;                   // output rows per wave
+    static constexpr int TH = RPW * NWAVE;                       // output rows per tile
+    static constexpr int HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
+    static constexpr int NTAPS = KS * KS, NKS = (NTAPS + 1) / 2;
+    static constexpr int HPIX = HH * HW;
+    static constexpr int HROWS_ALLOC = HH + 1;                   // one spare (zeroed) row: the odd tap past the end reads it
+    static constexpr int HB0 = HROWS_ALLOC * HW * 16, HB1 = (HPIX + 63) / 64 * 64 * 16;       // (the last DMA round is a whole 64 pixels)
+    static constexpr int HBYTES = (((HB0 > HB1 ? HB0 : HB1) + 1023) / 1024) * 1024;
+    static constexpr int WBYTES = NKS * 2 * 1024;                // B fragments: [ks][j][lane][8 halves]
+    static constexpr int EPI_BYTES = NWAVE * PATCH_BYTES;
+    static constexpr int LDS = WBYTES + (HBYTES > EPI_BYTES ? HBYTES : EPI_BYTES);
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, const int ntiles) {
+    using C = StemCfg<KS, S>;
+    constexpr int RPW = C::RPW, TH = C::TH, HW = C::HW, NKS = C::NKS, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wlds = smem;                         // weights
+    char* hbuf = smem + C::WBYTES;             // halo, later the transpose patches
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tiles_x = (d.OW + TW - 1) / TW, tiles_y = (d.OH + TH - 1) / TH, tpi = tiles_x * tiles_y;
+
+    // XCD-chunked persistent schedule (as conv_head7.hip)
+    const int per_xcd = (ntiles + 7) >> 3, SS = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int span_lo = xcd * per_xcd, span_hi = min(span_lo + per_xcd, ntiles);
+    int tile = span_lo + slot;
+    if (tile >= span_hi) return;
+
+    // weights -> LDS (fragment order, linear copy), spare halo row zeroed
+    for (int i = tid; i < C::WBYTES / 16; i += NT) *(float4*)(wlds + i * 16) = *(const float4*)((const char*)d.w_frag + i * 16);
+    for (int i = tid; i < C::HBYTES / 16; i += NT) *(float4*)(hbuf + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool refl = d.pad_reflect != 0;
+
+    // A fragment: pixel (row block i of this wave = output row wave*RPW + i, column fr), tap 2*ks + fh
+    const int a_base = ((wave * RPW * S) * HW + fr * S) * 16;
+    const int a_b16 = a_base + fh * 16;                          // second tap of the pair is the next pixel ...
+    const int a_bwrap = a_base + fh * (HW - (KS - 1)) * 16;      // ... or the first pixel of the next halo row
+
+    for (;;) {
+        const int n = tile / tpi, r = tile - n * tpi;
+        const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+        __syncthreads();                               // previous tile's transpose patches are done with the buffer
+        // ---- halo: one 16-byte word per pixel, 64 pixels per DMA instruction
+#pragma unroll 1
+        for (int j = 0; j < (C::HPIX + NT - 1) / NT; ++j) {
+            const int hp0 = min((j * NWAVE + wave) * 64, (C::HPIX - 1) / 64 * 64);      // (surplus rounds repeat the last one)
+            const int hp = min(hp0 + lane, C::HPIX - 1);
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = y0 * S - PAD + hy, ix = x0 * S - PAD + hx;
+            int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+            int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+            ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
+            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+            const f16* src = d.in + (long)((n * d.H + ry) * d.W + rx) * 8;
+            glds16((inb | refl) ? src : d.zeros, hbuf + hp0 * 16);
+        }
+        __syncthreads();                               // DMA landed (the barrier drains vmcnt) and visible
+
+        f32x16 acc[RPW][2];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        {
+            constexpr int PF = 3;                              // fragment sets in flight
+            f16x8 af[PF][RPW], bf[PF][2];
+            auto frags = [&](int ks, f16x8 (&a)[RPW], f16x8 (&b)[2]) {
+                const int t0 = 2 * ks, ty = t0 / KS, tx = t0 - ty * KS;
+                const bool wrap = tx == KS - 1;                // tap t0 + 1 starts the next kernel row
+                const int base = wrap ? a_bwrap : a_b16;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) a[i] = *(const f16x8*)(hbuf + base + ((i * S + ty) * HW + tx) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
+            };
+#pragma unroll
+            for (int p = 0; p < PF - 1; ++p) frags(p, af[p], bf[p]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + PF - 1 < NKS) frags(ks + PF - 1, af[(ks + PF - 1) % PF], bf[(ks + PF - 1) % PF]);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+            }
+        }
+        __syncthreads();                               // the halo has been consumed by every wave
+
+        // ---- epilogue: per 32-pixel row block through the wave's private patch
+        f16* patch = (f16*)(hbuf + wave * PATCH_BYTES);
+        float s1[8], s2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = j * 32 + 8 * g + 4 * fh;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d.bias) bv = *(const float4*)(d.bias + col);
+                    float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                    if (d.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
+                    *(f16x4*)(patch + fr * CP + col) = h;
+                }
+            const int oy = y0 + wave * RPW + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, px = idx >> 3, ch = idx & 7;
+                const f16x8 v = *(const f16x8*)(patch + px * CP + ch * 8);
+                const bool ok = (oy < d.OH) & (x0 + px < d.OW);
+                if (d.stats && ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[e] += f; s2[e] += f * f; }
+                }
+                if (ok) *(f16x8*)(d.out + ((long)((n * d.OH + oy) * d.OW + x0 + px) * 64 + ch * 8)) = v;
+            }
+        }
+        if (d.stats) {      // one 128-pixel record per wave (RPW == 4): lanes sharing a channel group in a fixed butterfly order
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int msk = 8; msk < 64; msk <<= 1) { s1[e] += __shfl_xor(s1[e], msk); s2[e] += __shfl_xor(s2[e], msk); }
+            if (lane < 8) {
+                float* dst = d.stats + ((long)(d.stats_tile_base + n * (tpi * NWAVE) + r * NWAVE + wave) * 2) * 64 + lane * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dst[e] = s1[e]; dst[64 + e] = s2[e]; }
+            }
+        }
+        tile += SS;
+        if (tile >= span_hi) break;
+    }
+}
+
+template <int KS, int S>
+int launch_stem(const ConvLaunch& d, hipStream_t stream) {
+    using C = StemCfg<KS, S>;
+    static_assert(2 * C::LDS <= 160 * 1024, "two workgroups per CU");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        GDT_CHECK_HIP(hipGetDevice(&dev));
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus / 8 * 8;
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    }
+    const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + C::TH - 1) / C::TH);
+    const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((conv_stem_kernel<KS, S>), dim3(grid), dim3(NT), C::LDS, stream, d, ntiles);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+}  // namespace
+
+// 8-channel (image) input, exactly 64 output channels, fp16 NHWC output, 7x7 (stride 1 or 2, pad 3) or 3x3 (stride 1, pad 1);
+// fused statistics need whole 128-pixel records per wave: stride 1 and OW % 32 == 0, OH % 16 == 0.
+bool gdt_conv_stem_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_STEM"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || !d.w_frag || d.Cin != 8 || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm) return false;
+    if (d.sy != d.sx || d.dys != 1 || d.dxs != 1 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
+    const bool k7 = d.ntaps == 49 && d.TW == 7 && d.dy0 == -3 && d.dx0 == -3 && (d.sy == 1 || d.sy == 2);
+    const bool k3 = d.ntaps == 9 && d.TW == 3 && d.dy0 == -1 && d.dx0 == -1 && d.sy == 1;
+    if (!k7 && !k3) return false;
+    if (d.pad_reflect && (d.H <= 3 || d.W <= 3)) return false;
+    if (d.stats && (d.sy != 1 || d.OW % 32 != 0 || d.OH % 16 != 0)) return false;
+    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+}
+
+int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream) {
+    if (d.ntaps == 9) return launch_stem<3, 1>(d, stream);
+    return d.sy == 1 ? launch_stem<7, 1>(d, stream) : launch_stem<7, 2>(d, stream);
+}

@@ -95,6 +95,8 @@ bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hi
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* variant);
+bool gdt_conv_stem_eligible(const ConvLaunch& d);          // conv_stem.hip (image -> 64 channels, variant 950000 + taps)
+int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_head7_eligible(const ConvLaunch& d);         // conv_head7.hip (fused 7x7 generator head, variant 920007)
 int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32

@@ -479,6 +479,19 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     }
             ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
             ph.has_frag = true;
+        } else if (!net->precision && cin_pad == 8 && o.cout_pad == 64 && cd.cout == 64 && !cd.transposed) {
+            // conv_stem.hip: one k-step = two taps x 8 channels; fragments [ks][column block j][lane][8], zero past the last tap
+            const int nks = (ph.ntaps + 1) / 2;
+            std::vector<f16> pf((size_t)nks * 2 * 64 * 8, (f16)0.f);
+            for (int ks = 0; ks < nks; ++ks)
+                for (int j = 0; j < 2; ++j)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = ks * 16 + (ln >> 5) * 8 + e;
+                            if (k < ph.Kpad) pf[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = pk[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + k];
+                        }
+            ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
+            ph.has_frag = true;
         }
     };
 

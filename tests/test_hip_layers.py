@@ -110,6 +110,45 @@ def test_generator_head_7x7_tanh(cuda_device, norm, shape):
     assert float((got - ref).abs().max()) < (3e-3 if norm else 1.5e-3)
 
 
+@pytest.mark.parametrize("cfg", [
+    # k, stride, reflect, relu, bn, norm_after, (n, h, w)
+    (7, 1, True, False, False, True, (4, 128, 128)),      # generator stem + InstanceNorm statistics from its epilogue
+    (7, 1, True, False, False, False, (3, 150, 171)),     # ragged tiles
+    (7, 2, False, True, True, False, (2, 384, 400)),      # ResNet-101 stem (BN folded, ReLU)
+    (3, 1, False, True, False, False, (2, 200, 180)),     # VGG16 conv1_1
+])
+def test_image_stem_kernels(cuda_device, cfg):
+    """conv_stem.hip: image (3 -> 8 channels) to 64 channels, 7x7 / 3x3, against torch on the fp16-rounded image."""
+    from gandtr_amd.engine import HipNet
+    k, stride, reflect, relu, bn, norm_after, (n, h, w) = cfg
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    wt = synth._normal(0, "ws", (64, 3, k, k), math.sqrt(2.0 / (3 * k * k)))
+    bias = synth._normal(0, "bs", (64,), 0.2)
+    bnp = None
+    if bn:
+        bnp = (synth._uniform(0, "g", (64,), 0.5, 1.5), synth._normal(0, "be", (64,), 0.2), synth._normal(0, "m", (64,), 0.2),
+               synth._uniform(0, "v", (64,), 0.5, 1.5))
+    o = net.conv(t, wt, bias, bn=bnp, stride=stride, pad=k // 2, reflect=reflect, relu=relu)
+    tap = net.output_nchw(o)
+    tap_n = net.output_nchw(net.instance_norm(o, relu=True)) if norm_after else None
+    net.finalize()
+    x = synth.synth_input(4, (n, 3, h, w))
+    outs = net.forward(x.to(cuda_device))
+    xin = x.half().float()
+    xi = F.pad(xin, (k // 2,) * 4, mode="reflect") if reflect else xin
+    ref = F.conv2d(xi, wt.half().float(), bias, stride=stride, padding=0 if reflect else k // 2)
+    if bn:
+        ref = F.batch_norm(ref, bnp[2], bnp[3], bnp[0], bnp[1], training=False, eps=1e-5)
+    if relu:
+        ref = F.relu(ref)
+    got = outs[tap].cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < (4e-3 if bn else 2e-3)
+    if norm_after:
+        assert _rel(outs[tap_n].cpu(), F.relu(F.instance_norm(got, eps=1e-5))) < 2e-3
+
+
 def test_resnet_block_chain_folds(cuda_device):
     """Three ResnetBlocks (p2p_networks.py:480-505) at 256 channels behind an InstanceNorm whose output feeds both the first
     conv and the first residual: exercises the folded norm with write-back (norm only, and norm + residual) of
