@@ -314,13 +314,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                         const int m = cur.tile_m * BM + row;
                         const bool ok = (m < d.M) & (col < d.Cout);
                         unsigned pix = (unsigned)m;                              // dense output grid: the GEMM row IS the pixel
-                        if (!dense) {                                            // (ConvTranspose2d phases: every other row / column)
+                        if (d.phase_cout) {                                      // fused transposed conv: column block -> sub-pixel
+                            const int mm = m < d.M ? m : 0;
+                            const int n = mm / hw_g, rem = mm - n * hw_g;
+                            const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+                            const int ph = col / d.phase_cout;
+                            pix = (unsigned)((n * d.OH + 2 * oy + (ph >> 1)) * d.OW + 2 * ox + (ph & 1));
+                            offs[qq] = ok ? pix * (unsigned)d.phase_cout + (col - ph * d.phase_cout) : 0u;
+                        } else if (!dense) {                                            // (ConvTranspose2d phases: every other row / column)
                             const int mm = m < d.M ? m : 0;
                             const int n = mm / hw_g, rem = mm - n * hw_g;
                             const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
                             pix = (unsigned)((n * d.OH + oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox);
                         }
-                        offs[qq] = ok ? pix * (unsigned)d.Cout + col : 0u;
+                        if (!d.phase_cout) offs[qq] = ok ? pix * (unsigned)d.Cout + col : 0u;
                         okmask |= (ok ? 1u : 0u) << qq;
                         if (has_res) rv[qq] = *(const f16x8*)(d.res + offs[qq]);   // offset 0 is a valid address for masked chunks
                     }
@@ -368,14 +375,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                 __syncthreads();
                 if (tid_e < BN * 2) {
                     const int rec = tid_e / BN, col = tid_e % BN;
-                    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + col) * 2]; t2 += F[((w * 2 + rec) * BN + col) * 2 + 1]; }
-                    const int gcol = cur.tile_n * BN + col;
                     const int grec = cur.tile_m * 2 + rec;
-                    if (gcol < d.Cout && grec * 128 < d.M) {
-                        float* dst = d.stats + ((long)(d.stats_tile_base + grec) * 2) * d.Cout + gcol;
-                        dst[0] = t1; dst[d.Cout] = t2;
+                    if (!d.phase_cout) {
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + col) * 2]; t2 += F[((w * 2 + rec) * BN + col) * 2 + 1]; }
+                        const int gcol = cur.tile_n * BN + col;
+                        if (gcol < d.Cout && grec * 128 < d.M) {
+                            float* dst = d.stats + ((long)(d.stats_tile_base + grec) * 2) * d.Cout + gcol;
+                            dst[0] = t1; dst[d.Cout] = t2;
+                        }
+                    } else if (col < d.phase_cout && grec * 128 < d.M) {
+                        // fused transposed conv: the sub-pixel phases held by this N tile are merged per channel; one record
+                        // set per N tile (the finalize kernel sums them like the phase launches' sets)
+                        float t1 = 0.f, t2 = 0.f;
+                        for (int c2 = col; c2 < BN; c2 += d.phase_cout)
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + c2) * 2]; t2 += F[((w * 2 + rec) * BN + c2) * 2 + 1]; }
+                        float* dst = d.stats + ((long)(cur.tile_n * (d.M / 128) + grec) * 2) * d.phase_cout + col;
+                        dst[0] = t1; dst[d.phase_cout] = t2;
                     }
                 }
             }
@@ -418,7 +436,8 @@ bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_IRB"); return e ? atoi(e) : 1; }();   // 0 off, 2 force
     if (mode == 0 || !d.w_frag || d.out_f32 || !d.out || d.Cin % 64 != 0 || d.Kpad != d.ntaps * d.Cin || d.Kpad < 128) return false;
     if (d.CoutPad % 64 != 0 || d.Cout % 8 != 0 || d.in_res || d.in_out) return false;
-    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * d.Cout >= (1L << 32)) return false;
+    if (d.phase_cout && (d.CoutPad % 256 != 0 || 256 % d.phase_cout != 0 || d.Cout != 4 * d.phase_cout || d.res || d.M % 128 != 0)) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * (d.phase_cout ? d.phase_cout : d.Cout) >= (1L << 32)) return false;
     if (d.stats && ((d.OHg * d.OWg) % 128 != 0 || d.CoutPad % 256 != 0)) return false;    // (narrower tiles with statistics: conv_igemm.hip measured faster)
     if (d.in_norm && (d.Cin > 256 || (d.OHg * d.OWg) % BM != 0)) return false;
     if (mode == 2) return true;
@@ -426,7 +445,7 @@ bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d) {
     // layer -- show this kernel ahead only where it also removes an InstanceNorm pass (Cin > 64 inputs the first kernel
     // cannot normalise while staging); on the plain 1x1 convs of ResNet-101 it is within +-3 % of conv_igemm.hip (whole net
     // 1526 vs 1545 descriptors/s) although the event-timed per-op profile had it 22 % faster (9.4 vs 12.1 ms over 58 launches).
-    if (mode == 1 && !d.in_norm) return false;
+    if (mode == 1 && !d.in_norm && !d.phase_cout) return false;
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
     return (long)((d.M + BM - 1) / BM) * (d.CoutPad / bn) >= 512;
 }

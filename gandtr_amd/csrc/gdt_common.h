@@ -69,6 +69,8 @@ struct ConvLaunch {
     int dbg;                      // timing-only ablation knob (env GDT_CONV_DBG): 1 skip staging loads, 2 skip MFMAs
     unsigned long long* stamp_out;  // diagnostic builds only (GDT_CONV_STAMP): per-wave s_memtime totals
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
+    int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
+                                  //      written to output pixel (2y + py, 2x + px); Cout / CoutPad count GEMM columns (conv_igemm_rb.hip)
 };
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>

@@ -52,6 +52,8 @@ struct Op {
     // CONV with few output channels written as fp32 NCHW (generator head): k x 1 implicit GEMM with kw*cout channels into a
     // scratch tensor + horizontal combine (rowsplit_combine_kernel)
     bool rowsplit = false; int rs_cout8 = 0; size_t rs_bias_off = 0;
+    // ConvTranspose2d(k3,s2,p1,op1) as ONE GEMM: columns = 4 sub-pixel phases x cout, K = 4 input shifts x cin (conv_igemm_rb.hip)
+    bool has_ctf = false; PackedPhase ctf; size_t ctf_bias_off = 0;
     // maxpool
     int k = 0, s = 0, p = 0;
     // gem
@@ -138,6 +140,8 @@ struct Step {
     int norm_into;   // INORM: index of the conv op that applies this normalisation while staging its input (-1: own apply pass)
     int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
     bool wb;         // INORM folded into a conv that also writes the normalised tensor out (residual / further consumers)
+    bool ctf;        // CONV (transposed): runs as the single fused-phase launch
+    int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
 
@@ -170,6 +174,14 @@ bool conv_fuses_stats(const Op& o, const Tensor& ti) {      // InstanceNorm part
     return hwg % 128 == 0;
 }
 
+// the fused-phase form of a transposed conv (see Op::ctf)
+void ctf_geometry(const gdt_net* net, const Op& o, int n, const Tensor& ti, ConvLaunch& d) {
+    conv_geometry(net, o, o.ctf, n, ti, d);
+    d.Cout = d.CoutPad = 4 * o.cd.cout; d.phase_cout = o.cd.cout;
+    d.OHg = ti.H; d.OWg = ti.W; d.sy = d.sx = 1; d.osy = d.osx = 2; d.ooy = d.oox = 0; d.pad_reflect = 0;
+    d.M = n * d.OHg * d.OWg;
+}
+
 // shape inference, fusion decisions and workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
 int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     auto& T = net->tensors;
@@ -177,7 +189,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].stats_sets = 1; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -206,6 +218,30 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         }
     }
 
+    // transposed convs: the single fused-phase launch when conv_igemm_rb.hip takes it
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        if (o.kind != OP_CONV) continue;
+        plan.steps[i].stats_sets = (int)o.phases.size();
+        if (!o.cd.transposed || !o.has_ctf || o.cd.out_f32_nchw) continue;
+        ConvLaunch d{};
+        ctf_geometry(net, o, N, T[o.in], d);
+        d.w_frag = (const f16*)net; d.out = (f16*)net;                                 // non-null markers only
+        d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
+        // GDT_CONV_CTF: 0 never, 1 (default) only where it lets the producer's InstanceNorm be folded in, 2 whenever eligible
+        static const int ctf_mode = [] { const char* e = getenv("GDT_CONV_CTF"); return e ? atoi(e) : 1; }();
+        bool want = ctf_mode == 2;
+        if (ctf_mode == 1) {                      // is the input an InstanceNorm (without residual) consumed only here?
+            for (int j = 0; j < i; ++j)
+                if (ops[j].kind == OP_INORM && ops[j].out == o.in && ops[j].res < 0) {
+                    int uses = 0;
+                    for (int k = 0; k < nops; ++k) uses += (ops[k].in == o.in) + (ops[k].res == o.in);
+                    ConvLaunch dn = d; dn.in_norm = (const float*)net;
+                    want = uses == 1 && gdt_conv_igemm_rb_eligible(dn);
+                }
+        }
+        if (want && gdt_conv_igemm_rb_eligible(d)) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = d.CoutPad / 256; }
+    }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
     static const bool allow_norm_fusion = [] { const char* e = getenv("GDT_NORM_FUSION"); return !e || atoi(e) != 0; }();
@@ -235,9 +271,16 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             if (k < 0) continue;
         }
         const Op& ok = ops[k];
-        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || ok.cd.transposed) continue;
+        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || (ok.cd.transposed && !plan.steps[k].ctf)) continue;
         if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
         ConvLaunch d{};
+        if (plan.steps[k].ctf) {
+            ctf_geometry(net, ok, N, T[ok.in], d);
+            d.w_frag = (const f16*)net; d.out = (f16*)net;
+            d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
+            if (!wb && irb_norm_ok(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            continue;
+        }
         conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
         if (ok.rowsplit) { d.Cout = ok.rs_cout8; d.out_f32 = nullptr; }
         d.w_lo = net->precision ? (const f16*)net : nullptr;                       // non-null marker only
@@ -290,7 +333,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 }
                 if (conv_fuses_stats(o, ti)) {
                     const int hwg = o.cd.transposed ? ti.H * ti.W : oh * conv_out_dim(o.cd, ti.W, o.cd.kw);
-                    const size_t tiles = (size_t)o.phases.size() * N * (hwg / 128);
+                    const size_t tiles = (size_t)st.stats_sets * N * (hwg / 128);
                     st.fused_stats = true; st.tiles_per_image = hwg / 128;
                     slab_bytes[i] = tiles * 2 * o.cd.cout * sizeof(float);
                     st.aux_off[0] = arena.alloc(slab_bytes[i]);
@@ -551,6 +594,40 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 });
                 o.phases.push_back(ph);
             }
+        if (!net->precision && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && residual_tensor < 0) {
+            // fused form: GEMM column = (py * 2 + px) * cout + co, k = (dy * 2 + dx) * cin + c over the 2x2 input shifts; a (shift,
+            // phase) pair that does not occur is a zero block (16 blocks, 9 non-zero)
+            PackedPhase& cf = o.ctf;
+            cf.ntaps = 4; cf.TW = 2; cf.dy0 = 0; cf.dys = 1; cf.dx0 = 0; cf.dxs = 1; cf.Kpad = 4 * cin_pad;
+            const int ncol = 4 * cd.cout, nks = cf.Kpad / 16;
+            std::vector<f16> pk((size_t)ncol * cf.Kpad, (f16)0.f);
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+                            if (ky < 0 || kx < 0) continue;
+                            for (int co = 0; co < cd.cout; ++co)
+                                for (int c = 0; c < cd.cin; ++c)
+                                    pk[(size_t)((py * 2 + px) * cd.cout + co) * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] =
+                                        (f16)(weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co]);
+                        }
+            std::vector<f16> pf(pk.size());
+            for (int cb = 0; cb < ncol / 32; ++cb)
+                for (int ks = 0; ks < nks; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const f16* src = pk.data() + (size_t)(cb * 32 + (ln & 31)) * cf.Kpad + ks * 16 + (ln >> 5) * 8;
+                        std::copy(src, src + 8, pf.data() + (((size_t)cb * nks + ks) * 64 + ln) * 8);
+                    }
+            cf.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
+            cf.has_frag = true;
+            if (has_shift) {
+                std::vector<float> b4(ncol);
+                for (int i = 0; i < ncol; ++i) b4[i] = shift[i % cd.cout];
+                o.ctf_bias_off = net->blob_append(b4.data(), b4.size() * sizeof(float));
+            }
+            o.has_ctf = true;
+        }
     }
     if (cd.out_f32_nchw) {
         o.slot = (int)net->out_ops.size();
@@ -781,6 +858,17 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
                 d.stats = stp.fused_stats ? (float*)(ws + stp.aux_off[0]) : nullptr;
+                if (stp.ctf) {                  // transposed conv as one fused-phase GEMM (conv_igemm_rb.hip)
+                    ctf_geometry(net, o, n, ti, d);
+                    d.bias = o.has_bias ? (const float*)(net->dev_blob + o.ctf_bias_off) : nullptr;
+                    d.out = tptr(o.out); d.out_f32 = nullptr;
+                    d.w = nullptr; d.w_lo = nullptr; d.w_frag = (const f16*)(net->dev_blob + o.ctf.w_frag_off);
+                    d.stats_tile_base = 0;
+                    int variant = 0;
+                    rc = gdt_launch_conv_igemm_rb(d, st, &variant);
+                    if (net->profiling) net->last_variant[stp.op] = variant;
+                    break;
+                }
                 int phase_idx = 0;
                 bool fused_head = false;
                 for (const PackedPhase& ph : o.phases) {
@@ -820,12 +908,12 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 const Tensor& ti = T[o.in];
                 if (stp.norm_into >= 0)     // the consuming conv applies it: only mean / rstd are produced here
                     rc = gdt_k_instance_norm_stats(tptr(o.in), f32, stp.fused_stats, (float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
-                                                   stp.fused_stats ? (int)net->ops[o.stats_from].phases.size() : 1,
+                                                   stp.fused_stats ? plan.steps[o.stats_from].stats_sets : 1,
                                                    (float*)(ws + stp.aux_off[1]), n, ti.H * ti.W, ti.C, o.eps, st);
                 else if (stp.fused_stats)
                     rc = gdt_k_instance_norm_fused(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), f32,
                                                    (const float*)(ws + stp.aux_off[0]), stp.tiles_per_image,
-                                                   (int)net->ops[o.stats_from].phases.size(), (float*)(ws + stp.aux_off[1]), n,
+                                                   plan.steps[o.stats_from].stats_sets, (float*)(ws + stp.aux_off[1]), n,
                                                    ti.H * ti.W, ti.C, o.eps, o.relu, st);
                 else
                     rc = gdt_k_instance_norm(tptr(o.in), o.res >= 0 ? tptr(o.res) : nullptr, tptr(o.out), f32, (float*)(ws + stp.aux_off[0]),

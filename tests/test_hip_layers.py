@@ -149,6 +149,34 @@ def test_image_stem_kernels(cuda_device, cfg):
         assert _rel(outs[tap_n].cpu(), F.relu(F.instance_norm(got, eps=1e-5))) < 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,fold", [(128, 64, True), (256, 128, False), (128, 64, False)])
+def test_transposed_conv_fused_phases(cuda_device, cin, cout, fold):
+    """ConvTranspose2d(k3, s2, p1, op1) (p2p_networks.py:289-300) as ONE GEMM over the four sub-pixel phases
+    (conv_igemm_rb.hip, phase_cout): plain, with the InstanceNorm statistics of its output taken in the epilogue, and with
+    the producer's InstanceNorm + ReLU folded into its input staging."""
+    from gandtr_amd.engine import HipNet
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "w0", (cin, 3, 3, 3), 0.4), pad=1, reflect=True)
+    tap_in = net.output_nchw(a)
+    u = net.instance_norm(a, relu=True) if fold else a
+    wt, b = synth._normal(0, "wt", (cin, cout, 3, 3), math.sqrt(2.0 / (cin * 2.25))), synth._normal(0, "bt", (cout,), 0.2)
+    o = net.conv(u, wt, b, stride=2, pad=1, transposed=True)
+    tap = net.output_nchw(o)
+    tap_n = net.output_nchw(net.instance_norm(o, relu=True))
+    net.finalize()
+    x = synth.synth_input(6, (32, 3, 64, 64))          # 512 tiles of 256 GEMM rows: the persistent kernel is eligible
+    outs = net.forward(x.to(cuda_device))
+    xin = outs[tap_in].cpu()
+    if fold:
+        xin = F.relu(F.instance_norm(xin, eps=1e-5)).half().float()
+    ref = F.conv_transpose2d(xin, wt.half().float(), b, stride=2, padding=1, output_padding=1)
+    got = outs[tap].cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < (3e-3 if fold else 2e-3)
+    assert _rel(outs[tap_n].cpu(), F.relu(F.instance_norm(got, eps=1e-5))) < 2e-3
+
+
 def test_resnet_block_chain_folds(cuda_device):
     """Three ResnetBlocks (p2p_networks.py:480-505) at 256 channels behind an InstanceNorm whose output feeds both the first
     conv and the first residual: exercises the folded norm with write-back (norm only, and norm + residual) of
