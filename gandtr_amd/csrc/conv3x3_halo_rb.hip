@@ -267,7 +267,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[cu][i], b[kk][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                     load_b(kk, ntile_n, noff);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -289,35 +289,43 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         // residual.  Its first barrier is also the chunk barrier that publishes the next tile's first halo stage.
         if (!(d.dbg & 4)) {
             if (nchunks == 1) __syncthreads();          // (no chunk barrier separates this tile from the previous epilogue's reads)
+            // MFMA operands are swapped (D = W * A^T): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3,
+            // the four consecutive output channels 8g + 4fh .. +3 of column block j -- 8-byte LDS writes (32 per lane and tile
+            // instead of 128 two-byte ones, see conv_igemm_rb.hip).  InstanceNorm statistics are taken in the store phase from
+            // the fp16 values that are written out (each thread owns one 8-channel group), merged in a fixed order.
             constexpr int CP = BN + 8, HM = BM / 2, CPR = BN / 8, NCH = HM * CPR / NT;
             f16* Ct = (f16*)(smem + C_OFF);
             const bool relu_now = d.relu && !d.res;
             const bool has_res = d.res != nullptr;
-            float s1[TN], s2[TN];
+            int fr_e = fr, fh_e = fh, tid_e = tid;              // (opaque copies: keeps the epilogue's addresses out of the
+            asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(tid_e));   //  persistent loop's invariant set, where they would spill)
+            float st1[2][8], st2[2][8];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st1[r][e] = 0.f; st2[r][e] = 0.f; }
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 if (p == 1) __syncthreads();                   // the stores of the first half have read the region
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = wn * WTN + j * 32 + fr;
-                    const float bv = d.bias ? d.bias[cur.tile_n * BN + col] : 0.f;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int ii = 0; ii < TM / 2; ++ii)
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wn * WTN + j * 32 + 8 * g + 4 * fh_e;
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (d.bias) bv = *(const float4*)(d.bias + cur.tile_n * BN + col);
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int rr = wm * (WTM / 2) + ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                            float v = acc[p * (TM / 2) + ii][j][e] + bv;
-                            s1[j] += v; s2[j] += v * v;
-                            if (relu_now) v = fmaxf(v, 0.f);
-                            Ct[rr * CP + col] = (f16)v;
+                        for (int ii = 0; ii < TM / 2; ++ii) {
+                            const int rr = wm * (WTM / 2) + ii * 32 + fr_e;
+                            const f32x16& a = acc[p * (TM / 2) + ii][j];
+                            float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
+                            if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
+                            *(f16x4*)(Ct + rr * CP + col) = h;
                         }
-                }
+                    }
                 __syncthreads();
-                // residual loads are issued in batches ahead of their use (conv_epilogue.h); two batches keep the register
-                // footprint next to the live half of the accumulators and the prefetched weights small
-                constexpr int QB = NCH / 2;
+                constexpr int QB = NCH / 2;                     // residual loads in flight per thread
 #pragma unroll
                 for (int qb = 0; qb < NCH; qb += QB) {
                     unsigned offs[QB];
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                     unsigned okmask = 0;
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
-                        const int id = (qb + q) * NT + tid;
+                        const int id = (qb + q) * NT + tid_e;
                         const int rr = id / CPR;
                         const int row = (rr / (WTM / 2)) * WTM + p * (WTM / 2) + (rr % (WTM / 2));
                         const int col = cur.tile_n * BN + (id % CPR) * 8;
@@ -337,8 +345,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                     }
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
-                        const int id = (qb + q) * NT + tid;
+                        const int id = (qb + q) * NT + tid_e;
                         f16x8 v = *(const f16x8*)(Ct + (id / CPR) * CP + (id % CPR) * 8);
+                        if (d.stats) {
+                            const int rec = (qb + q) >= NCH / 2 ? 1 : 0;        // (compile-time after unrolling: region rows are wave-major)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; st1[rec][e] += f; st2[rec][e] += f * f; }
+                        }
                         if (has_res) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
@@ -351,13 +364,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                     }
                 }
             }
-            if (d.stats) {      // one 128-row record per wave row: per-lane column sums, the two half-waves combined
+            if (d.stats) {      // one 128-row record per wave row: lanes sharing a channel group, then the 8 waves, fixed order
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float t1 = s1[j] + __shfl_xor(s1[j], 32), t2 = s2[j] + __shfl_xor(s2[j], 32);
-                    const int gcol = cur.tile_n * BN + wn * WTN + j * 32 + fr;
-                    if (fh == 0 && gcol < d.Cout) {
-                        float* dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + gcol;
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st1[r][e] += __shfl_xor(st1[r][e], 32); st2[r][e] += __shfl_xor(st2[r][e], 32); }
+                __syncthreads();                                   // every read of the transpose region is done: reuse it
+                float* F = (float*)Ct;                             // [wave][record][BN][2]
+                if ((tid_e & 63) < CPR) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float* f = F + (((tid_e >> 6) * 2 + r) * BN + (tid_e & 63) * 8 + e) * 2;
+                            f[0] = st1[r][e]; f[1] = st2[r][e];
+                        }
+                }
+                __syncthreads();
+                if (tid_e < BN * 2) {
+                    const int rec = tid_e / BN, col = tid_e % BN;
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + col) * 2]; t2 += F[((w * 2 + rec) * BN + col) * 2 + 1]; }
+                    const int gcol = cur.tile_n * BN + col;
+                    if (gcol < d.Cout) {
+                        float* dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + rec) * 2) * d.Cout + gcol;
                         dst[0] = t1; dst[d.Cout] = t2;
                     }
                 }
