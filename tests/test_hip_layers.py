@@ -76,6 +76,20 @@ def test_conv_layer(cuda_device, cfg):
     assert _rel(got, ref) < tol, (cfg, _rel(got, ref))
 
 
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, reflect, relu, bn, (n, h, w)          -- sizes with >= 512 (patch, N tile) pairs: conv3x3_halo_rb.hip runs
+    (256, 256, False, True, False, (8, 128, 128)),     # VGG-style zero padding + bias + ReLU
+    (256, 256, True, False, False, (9, 60, 128)),      # ragged patch rows (60 = 3 x 16 + 12), reflect padding
+    (128, 512, False, True, True, (8, 96, 96)),        # two N tiles, folded BN, 2 input chunks
+    (64, 256, False, False, False, (32, 64, 64)),      # single 64-channel chunk (no chunk barrier between tiles)
+])
+def test_conv3x3_persistent_halo_kernel(cuda_device, cfg):
+    cin, cout, reflect, relu, bn, (n, h, w) = cfg
+    got, ref = _run_single_conv(cuda_device, cin, cout, 3, 1, 1, reflect, False, relu, bn, n=n, h=h, w=w)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < (4e-3 if bn else 2e-3), (cfg, _rel(got, ref))
+
+
 def test_conv_ragged_tail(cuda_device):
     """M not a multiple of the 128-row tile and odd spatial sizes."""
     got, ref = _run_single_conv(cuda_device, 64, 64, 3, 1, 1, True, False, True, False, n=3, h=13, w=17)
@@ -195,7 +209,7 @@ def test_resnet_block_chain_folds(cuda_device):
         y = net.instance_norm(net.conv(u, w2, pad=1, reflect=True), relu=False, residual=y)
     out = net.output_nchw(y)
     net.finalize()
-    x = synth.synth_input(5, (16, 3, 32, 32))          # 16 images x 4 patches: enough tiles for the LDS-resident kernels
+    x = synth.synth_input(5, (32, 3, 64, 64))          # 32 images x 16 patches = 512 tiles: the persistent halo kernel is eligible
     outs = net.forward(x.to(cuda_device))
     r = F.relu(F.instance_norm(outs[tap].cpu(), eps=1e-5))
     q = lambda v: v.half().float()
