@@ -47,7 +47,7 @@ constexpr size_t irb_lds_bytes() { return (size_t)C_OFF + (size_t)irb_region_row
 
 struct TileAt { int tile_m, tile_n; bool valid; };
 
-template <int BN, int WGM, int WGN, bool NORM>
+template <int BN, int WGM, int WGN, bool NORM, bool CTF = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const ConvLaunch d, const int vblocks) {
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8, AR = BM / RPR;      // 512 threads, 64 rows per loader round, 4 rounds
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -209,8 +209,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        int c_tap = 0, c_chunk = 0;                   // (CTF) input shift of the current K-step
         for (int s = 0; s < nk; ++s) {
             const bool last = s + 1 == nk;
+            // fused transposed conv: the (shift, phase) weight block of column block j is all zero unless the phase uses the
+            // shift (phase 0: shift 0; 1: dx; 2: dy; 3: all) -- those MFMAs are skipped (wave-uniform, no memory operation in
+            // the branch, so the counted waits stay exact).  Phases of this wave's two column blocks: gdt_ctf_column().
+            bool use_j[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) use_j[j] = true;
+            if (CTF) {
+                const int pair = ((cur.tile_n * WGN + wn) / (d.phase_cout >> 5)) & 1;
+                const unsigned m0 = pair == 0 ? 0x1u : 0x3u, m1 = pair == 0 ? 0xFu : 0x5u;     // shift masks of phases (0 | 1), (3 | 2)
+                use_j[0] = (m0 >> c_tap) & 1u;
+                if (TN > 1) use_j[TN - 1] = (m1 >> c_tap) & 1u;
+                if (++c_chunk == cpt) { c_chunk = 0; ++c_tap; }
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int cu = kk & 1, nx = cu ^ 1;
@@ -221,10 +235,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                 if (kk == 1) store_pend(pend, A_BYTES - so);             // A of the next step (loaded one step ago)
                 if (kk == 2) { if (!(d.dbg & 2)) pend = load_pend(); advance(); }          // A of the step after it
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
+                    if (!CTF || use_j[j]) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+                        for (int i = 0; i < TM; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+                    }
                 if (!last && !(d.dbg & 1)) load_b(kk, cur.tile_n, s + 1);       // (the next TILE's first slice is fetched after the epilogue:
                 __builtin_amdgcn_sched_barrier(0);              //  32 registers the epilogue needs)
             }
@@ -318,9 +334,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                             const int mm = m < d.M ? m : 0;
                             const int n = mm / hw_g, rem = mm - n * hw_g;
                             const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
-                            const int ph = col / d.phase_cout;
+                            int ph, co;
+                            gdt_ctf_column(col, d.phase_cout, ph, co);
                             pix = (unsigned)((n * d.OH + 2 * oy + (ph >> 1)) * d.OW + 2 * ox + (ph & 1));
-                            offs[qq] = ok ? pix * (unsigned)d.phase_cout + (col - ph * d.phase_cout) : 0u;
+                            offs[qq] = ok ? pix * (unsigned)d.phase_cout + co : 0u;
                         } else if (!dense) {                                            // (ConvTranspose2d phases: every other row / column)
                             const int mm = m < d.M ? m : 0;
                             const int n = mm / hw_g, rem = mm - n * hw_g;
@@ -389,9 +406,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                         // fused transposed conv: the sub-pixel phases held by this N tile are merged per channel; one record
                         // set per N tile (the finalize kernel sums them like the phase launches' sets)
                         float t1 = 0.f, t2 = 0.f;
-                        for (int c2 = col; c2 < BN; c2 += d.phase_cout)
+                        for (int blk = 0; blk < BN / 32; ++blk) {           // column blocks of this N tile that hold channel `col`
+                            int ph, co;
+                            gdt_ctf_column(cur.tile_n * BN + blk * 32 + (col & 31), d.phase_cout, ph, co);
+                            if (co != col) continue;
+                            const int c2 = blk * 32 + (col & 31);
 #pragma unroll
                             for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + c2) * 2]; t2 += F[((w * 2 + rec) * BN + c2) * 2 + 1]; }
+                        }
                         float* dst = d.stats + ((long)(cur.tile_n * (d.M / 128) + grec) * 2) * d.phase_cout + col;
                         dst[0] = t1; dst[d.phase_cout] = t2;
                     }
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
     }
 }
 
-template <int BN, int WGM, int WGN, bool NORM>
+template <int BN, int WGM, int WGN, bool NORM, bool CTF = false>
 int launch_irb(const ConvLaunch& d, hipStream_t stream) {
     constexpr size_t lds = irb_lds_bytes<BN, WGM>();
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -418,11 +440,11 @@ int launch_irb(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_rb_kernel<BN, WGM, WGN, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_rb_kernel<BN, WGM, WGN, NORM, CTF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int vblocks = gdt_grid_for_tiles((d.M + BM - 1) / BM, d.CoutPad / BN);
     const int grid = vblocks < cus ? vblocks : cus;
-    hipLaunchKernelGGL((conv_igemm_rb_kernel<BN, WGM, WGN, NORM>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
+    hipLaunchKernelGGL((conv_igemm_rb_kernel<BN, WGM, WGN, NORM, CTF>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -436,7 +458,7 @@ bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_IRB"); return e ? atoi(e) : 1; }();   // 0 off, 2 force
     if (mode == 0 || !d.w_frag || d.out_f32 || !d.out || d.Cin % 64 != 0 || d.Kpad != d.ntaps * d.Cin || d.Kpad < 128) return false;
     if (d.CoutPad % 64 != 0 || d.Cout % 8 != 0 || d.in_res || d.in_out) return false;
-    if (d.phase_cout && (d.CoutPad % 256 != 0 || 256 % d.phase_cout != 0 || d.Cout != 4 * d.phase_cout || d.res || d.M % 128 != 0)) return false;
+    if (d.phase_cout && (d.CoutPad % 256 != 0 || 256 % d.phase_cout != 0 || d.phase_cout < 64 || d.Cout != 4 * d.phase_cout || d.res || d.M % 128 != 0)) return false;
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * (d.phase_cout ? d.phase_cout : d.Cout) >= (1L << 32)) return false;
     if (d.stats && ((d.OHg * d.OWg) % 128 != 0 || d.CoutPad % 256 != 0)) return false;    // (narrower tiles with statistics: conv_igemm.hip measured faster)
     if (d.in_norm && (d.Cin > 256 || (d.OHg * d.OWg) % BM != 0)) return false;
@@ -456,6 +478,7 @@ int gdt_launch_conv_igemm_rb(const ConvLaunch& d_in, hipStream_t stream, int* va
     d.dbg = dbg;
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
     *variant = 940000 + bn;
+    if (d.phase_cout) return d.in_norm ? launch_irb<256, 2, 4, true, true>(d, stream) : launch_irb<256, 2, 4, false, true>(d, stream);
     if (d.in_norm) {
         if (bn == 256) return launch_irb<256, 2, 4, true>(d, stream);
         if (bn == 128) return launch_irb<128, 4, 2, true>(d, stream);

@@ -97,6 +97,15 @@ bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hi
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* variant);
+// fused transposed conv (phase_cout > 0): GEMM column c -> (sub-pixel phase, output channel).  Each 64-column wave slice pairs
+// a cheap phase with an expensive one -- 32 columns of phase 0 (1 input shift) + 32 of phase 3 (4 shifts), or 1 + 2 (2 + 2) --
+// so that skipping the all-zero (shift, phase) weight blocks leaves every wave 4-5 of its 8 block-steps.
+inline __host__ __device__ void gdt_ctf_column(int c, int phase_cout, int& phase, int& co) {
+    const int wq = c >> 6, j = (c >> 5) & 1, wpp = phase_cout >> 5;      // wave slice index, block in slice, slices per pair
+    const int pair = (wq / wpp) & 1;
+    phase = pair == 0 ? (j ? 3 : 0) : (j ? 2 : 1);
+    co = (wq % wpp) * 32 + (c & 31);
+}
 bool gdt_conv_stem_eligible(const ConvLaunch& d);          // conv_stem.hip (image -> 64 channels, variant 950000 + taps)
 int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_head7_eligible(const ConvLaunch& d);         // conv_head7.hip (fused 7x7 generator head, variant 920007)

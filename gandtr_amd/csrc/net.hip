@@ -594,24 +594,26 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 });
                 o.phases.push_back(ph);
             }
-        if (!net->precision && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && residual_tensor < 0) {
-            // fused form: GEMM column = (py * 2 + px) * cout + co, k = (dy * 2 + dx) * cin + c over the 2x2 input shifts; a (shift,
-            // phase) pair that does not occur is a zero block (16 blocks, 9 non-zero)
+        if (!net->precision && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && cd.cout >= 64 && residual_tensor < 0) {
+            // fused form: GEMM column -> (phase py * 2 + px, co) by gdt_ctf_column(), k = (dy * 2 + dx) * cin + c over the 2x2 input
+            // shifts; a (shift, phase) pair that does not occur is a zero block (16 blocks, 9 non-zero) the kernel skips
             PackedPhase& cf = o.ctf;
             cf.ntaps = 4; cf.TW = 2; cf.dy0 = 0; cf.dys = 1; cf.dx0 = 0; cf.dxs = 1; cf.Kpad = 4 * cin_pad;
             const int ncol = 4 * cd.cout, nks = cf.Kpad / 16;
             std::vector<f16> pk((size_t)ncol * cf.Kpad, (f16)0.f);
-            for (int py = 0; py < 2; ++py)
-                for (int px = 0; px < 2; ++px)
-                    for (int dy = 0; dy < 2; ++dy)
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
-                            if (ky < 0 || kx < 0) continue;
-                            for (int co = 0; co < cd.cout; ++co)
-                                for (int c = 0; c < cd.cin; ++c)
-                                    pk[(size_t)((py * 2 + px) * cd.cout + co) * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] =
-                                        (f16)(weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co]);
-                        }
+            for (int col = 0; col < ncol; ++col) {
+                int phase, co;
+                gdt_ctf_column(col, cd.cout, phase, co);
+                const int py = phase >> 1, px = phase & 1;
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+                        if (ky < 0 || kx < 0) continue;
+                        for (int c = 0; c < cd.cin; ++c)
+                            pk[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] =
+                                (f16)(weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co]);
+                    }
+            }
             std::vector<f16> pf(pk.size());
             for (int cb = 0; cb < ncol / 32; ++cb)
                 for (int ks = 0; ks < nks; ++ks)
@@ -623,7 +625,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             cf.has_frag = true;
             if (has_shift) {
                 std::vector<float> b4(ncol);
-                for (int i = 0; i < ncol; ++i) b4[i] = shift[i % cd.cout];
+                for (int i = 0; i < ncol; ++i) { int ph, co; gdt_ctf_column(i, cd.cout, ph, co); b4[i] = shift[co]; }
                 o.ctf_bias_off = net->blob_append(b4.data(), b4.size() * sizeof(float));
             }
             o.has_ctf = true;
