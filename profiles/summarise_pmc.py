@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
-    m = re.search(r"(conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
         return re.sub(r"^_ZN\d+_GLOBAL__N_\d+", "", name)[:48]
     base, args = m.group(1), m.group(2)
@@ -27,6 +27,8 @@ def short(name):
         return "%s<%s>" % (base, a[1])
     if base == "conv3x3_halo_rb_kernel":
         return "%s<%s>[mode %s]" % (base, a[0], a[3])
+    if base == "conv_stem_kernel":
+        return "%s<%d taps>" % (base, int(a[0]) ** 2)
     if base == "conv_igemm_rb_kernel":
         return "%s<%s>%s" % (base, a[0], "[norm]" if a[3] == "true" else "")
     return "%s<%s>" % (base, a[0])
