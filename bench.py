@@ -50,6 +50,8 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 960000:
+        return "conv3x3_halo_rb_kernel<256>[transposed]"
     if variant >= 950000:
         return "conv_stem_kernel<%d taps>" % (variant - 950000)
     if variant >= 940000:

@@ -73,12 +73,21 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 // MODE bits: 1 = the producer's InstanceNorm (+ReLU) is applied while staging; 2 = ... plus a residual; 4 = the transformed
 // tensor is written back (it has further consumers).  Built: 0, 1, 5 (norm + write-back), 7 (norm + residual + write-back:
 // the ResnetBlock output folded into the next block's first conv).
-template <int BN, int WGM, int WGN, int MODE>
+// CT = true: ConvTranspose2d(k3, s2, p1, op1) (p2p_networks.py:289-300) on the same machinery.  The 16x16 patch is a patch of
+// INPUT pixels with a 17x17 halo (one extra row / column, zero past the image); the "taps" are the four input shifts (dy, dx);
+// the GEMM columns are the four sub-pixel phases x cout in the paired order of gdt_ctf_column() (weights: Op::ctf in net.hip),
+// and a wave skips the (shift, phase) blocks that are all zero; the epilogue scatters column blocks to output pixels
+// (2y + py, 2x + px).  MODE 3 (norm + residual, no write-back) exists for this form: y9 = y8 + IN(.) feeds only the first
+// transposed conv.
+template <int BN, int WGM, int WGN, int MODE, bool CT = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
     constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
-    constexpr int NR = (HALO_ROWS_PAD + RPR - 1) / RPR;
-    static_assert(NR <= 7, "halo rounds are spread over the taps of the previous chunk");
+    constexpr int HW_ = CT ? 17 : HALO_W;                               // halo width / height
+    constexpr int HROWS = HW_ * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;   // 324 / 328, or 289 / 296
+    constexpr int NTAP = CT ? 4 : 9, RPS = CT ? 2 : 1;                  // steps per chunk, staging rounds per step
+    constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
+    static_assert(NR <= (NTAP - 1) * RPS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the steps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 2 && TM % 2 == 0 && TN >= 1 && WTM == 128, "tile shape (one 128-row statistics record per wave row)");
@@ -117,9 +126,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         // round get spilled, and every scratch reload is a vmcnt(0) of its own)
         int lr = lrow;
         asm volatile("" : "+v"(lr));
-        const int h = min(r * RPR + lr, HALO_ROWS_PAD - 1);        // rows past the padded halo repeat its last (all-zero) row
-        const int hy = (h * 3641) >> 16, hx = h - hy * HALO_W;       // h / 18 for h < 2^12
-        const int iy = ta.y0 - 1 + hy, ix = ta.x0 - 1 + hx;
+        const int h = min(r * RPR + lr, HROWS_PAD - 1);            // rows past the padded halo repeat its last (all-zero) row
+        const int hy = (h * (CT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;       // h / 17 or h / 18 for h < 2^9
+        const int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
         int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
         int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
         ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);          // always a valid pixel
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         const int q = (lane & 7) ^ ((hx >> 1) & 7);
         Pend p;
         p.goff = ((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + 3)) + (chunk * 8 + q) * 8;      // element offset (< 2^32, checked on the host)
-        p.ok = (h < HALO_ROWS) & (inb | refl);
+        p.ok = (h < HROWS) & (inb | refl);
         p.raw = *(const f16x8*)(d.in + p.goff);
         if (RES) p.res = *(const f16x8*)(d.in_res + p.goff);
         return p;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         if (tid < 4) *(float4*)(nlds + ZERO_ENTRY + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto store_piece = [&](int slot, int stage_off, int r, const Pend& p) {
-        const int row = min(r * RPR + lrow, HALO_ROWS_PAD - 1);
+        const int row = min(r * RPR + lrow, HROWS_PAD - 1);
         f16x8 o, z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) z[e] = (f16)0.f;
@@ -174,10 +183,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         // The transformed tensor is materialised as a side effect (MODE bit 4).  EVERY piece stores the value of its (clamped,
         // reflected) source pixel, halo pieces included: neighbouring patches write identical bits to the same place, which
         // is cheaper than a conditional store (27 % more store traffic, no branch in the loop).
-        if (WB) {
-            *(f16x8*)(d.in_out + p.goff) = o;
-            o = p.ok ? o : z;
-        }
+        if (WB) *(f16x8*)(d.in_out + p.goff) = o;
+        if (WB || RES) o = p.ok ? o : z;        // (the zero table entry does not cancel a residual)
         *(f16x8*)(smem + stage_off + row * ROWB + ((lane & 7) << 4)) = o;
     };
 
@@ -197,9 +204,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
     int vt[3];
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
-        vt[tx] = ((wm * (WTM / 16) + (fr >> 4)) * HALO_W + (fr & 15)) * ROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 7)) << 4);
+        vt[tx] = ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * ROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 7)) << 4);
     auto a_frag = [&](int stage_off, int i, int ty, int tx, int kk) -> f16x8 {
-        return *(const f16x8*)(smem + ((vt[tx] + stage_off) ^ (kk << 5)) + (i * 2 * HALO_W + ty * HALO_W + tx) * ROWB);
+        return *(const f16x8*)(smem + ((vt[tx] + stage_off) ^ (kk << 5)) + (i * 2 * HW_ + ty * HW_ + tx) * ROWB);
     };
 
     const int nchunks = d.Cin >> 6;
@@ -213,7 +220,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
 #pragma unroll
     for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
     __syncthreads();
-    Pend pend = load_piece(cur, 0, 0);               // (placeholder value: overwritten before its first use)
+    Pend pend[RPS];
+#pragma unroll
+    for (int u = 0; u < RPS; ++u) pend[u] = load_piece(cur, 0, 0);      // (placeholder values: overwritten before their first use)
 
     f16x8 afr[2][TM];
 #pragma unroll
@@ -240,34 +249,42 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             const int sc = last ? 0 : c + 1, sslot = to_next ? slot ^ 1 : slot;
             // the next tile's (scale, shift) table goes in one chunk ahead of its first use (published by this chunk's barrier)
             if (NORM && nxt.valid && c == nchunks - 2) stage_norm(nxt, slot ^ 1);
+            // (CT) which of this wave's two column blocks have a non-zero weight block for input shift t
+            const int ct_pair = CT ? (((cur.tile_n * WGN + wn) / (d.phase_cout >> 5)) & 1) : 0;
+            const unsigned ct_m0 = ct_pair == 0 ? 0x1u : 0x3u, ct_m1 = ct_pair == 0 ? 0xFu : 0x5u;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ty = t / 3, tx = t - ty * 3;
-                const int nty = (t + 1) / 3, ntx = (t + 1) - nty * 3;         // next tap of this chunk (t < 8)
+            for (int t = 0; t < NTAP; ++t) {
+                const int ty = CT ? (t >> 1) : t / 3, tx = CT ? (t & 1) : t - ty * 3;
+                const int nty = CT ? ((t + 1) >> 1) : (t + 1) / 3, ntx = CT ? ((t + 1) & 1) : (t + 1) - nty * 3;     // next tap of this chunk
                 // K offset of the next step's weight slice
                 // (after the very last step this fetches the first slice again: unconditional loads keep the code straight-line,
                 // which is what lets the compiler wait with exact vmcnt counts instead of vmcnt(0))
-                const long noff = (long)(t < 8 ? (t + 1) * cin16 + c * 4 : sc * 4) * 512;
-                const int ntile_n = (t == 8 && last) ? nxt.tile_n : cur.tile_n;         // (tile_at: 0 when there is no next tile)
+                const long noff = (long)(t < NTAP - 1 ? (t + 1) * cin16 + c * 4 : sc * 4) * 512;
+                const int ntile_n = (t == NTAP - 1 && last) ? nxt.tile_n : cur.tile_n;         // (tile_at: 0 when there is no next tile)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int cu = kk & 1, nx = cu ^ 1;
                     if (kk < 3) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, ty, tx, kk + 1);
-                    } else if (t < 8) {                   // first fragments of the next tap: same halo stage, no barrier between
+                    } else if (t < NTAP - 1) {            // first fragments of the next tap: same halo stage, no barrier between
 #pragma unroll
                         for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, nty, ntx, 0);
                     }
-                    if (kk == 2) {               // halo of the next chunk: one piece per tap step, written a step after its load
-                        if (t >= 1 && t <= NR) store_piece(sslot, A_BYTES - so, t - 1, pend);
-                        if (t < NR) pend = load_piece(sta, sc, t);
+                    if (kk == 2) {               // halo of the next chunk: RPS pieces per step, written a step after their load
+#pragma unroll
+                        for (int u = 0; u < RPS; ++u) {
+                            if (t >= 1 && (t - 1) * RPS + u < NR) store_piece(sslot, A_BYTES - so, (t - 1) * RPS + u, pend[u]);
+                            if (t * RPS + u < NR) pend[u] = load_piece(sta, sc, t * RPS + u);
+                        }
                     }
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j)
+                        if (!CT || (((j == 0 ? ct_m0 : ct_m1) >> t) & 1u)) {           // (wave-uniform; no memory operation inside)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+                            for (int i = 0; i < TM; ++i)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+                        }
                     load_b(kk, ntile_n, noff);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -339,7 +356,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                         const int col = cur.tile_n * BN + (id % CPR) * 8;
                         const int y = cur.y0 + (row >> 4), x = cur.x0 + (row & 15);
                         const bool ok = (y < d.H) & (x < d.W) & (col < d.Cout);
-                        offs[q] = ok ? (unsigned)(((cur.n * d.H + y) * d.W + x) * d.Cout + col) : 0u;
+                        if (!CT) {
+                            offs[q] = ok ? (unsigned)(((cur.n * d.H + y) * d.W + x) * d.Cout + col) : 0u;
+                        } else {                        // column block -> sub-pixel phase of the 2x up-sampled output
+                            int ph, co;
+                            gdt_ctf_column(col, d.phase_cout, ph, co);
+                            offs[q] = ok ? (unsigned)(((cur.n * d.OH + 2 * y + (ph >> 1)) * d.OW + 2 * x + (ph & 1)) * d.phase_cout + co) : 0u;
+                        }
                         okmask |= (ok ? 1u : 0u) << q;
                         if (has_res) rv[q] = *(const f16x8*)(d.res + offs[q]);    // offset 0 is a valid address for masked chunks
                     }
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                         }
                 }
                 __syncthreads();
-                if (tid_e < BN * 2) {
+                if (!CT && tid_e < BN * 2) {
                     const int rec = tid_e / BN, col = tid_e % BN;
                     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -391,6 +414,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                         float* dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + rec) * 2) * d.Cout + gcol;
                         dst[0] = t1; dst[d.Cout] = t2;
                     }
+                }
+                if (CT && tid_e < d.phase_cout * 2) {
+                    // the sub-pixel phases held by this N tile are merged per channel; one record set per N tile (the
+                    // finalize kernel sums the sets like it sums the phase launches' sets)
+                    const int rec = tid_e / d.phase_cout, col = tid_e % d.phase_cout;
+                    float t1 = 0.f, t2 = 0.f;
+                    for (int blk = 0; blk < BN / 32; ++blk) {
+                        int ph, co;
+                        gdt_ctf_column(cur.tile_n * BN + blk * 32 + (col & 31), d.phase_cout, ph, co);
+                        if (co != col) continue;
+                        const int c2 = blk * 32 + (col & 31);
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + c2) * 2]; t2 += F[((w * 2 + rec) * BN + c2) * 2 + 1]; }
+                    }
+                    float* dst = d.stats + ((long)(cur.tile_n * (ntm * WGM) + cur.tile_m * WGM + rec) * 2) * d.phase_cout + col;
+                    dst[0] = t1; dst[d.phase_cout] = t2;
                 }
             }
         } else {                         // ablation: no epilogue (keep the accumulators observable)
@@ -412,7 +451,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
     }
 }
 
-template <int BN, int WGM, int WGN, int MODE>
+template <int BN, int WGM, int WGN, int MODE, bool CT = false>
 int launch_rb(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
     constexpr size_t lds = rb_lds_bytes<BN>();
@@ -423,12 +462,12 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     static const int persist = [] { const char* e = getenv("GDT_RB_PERSIST"); return e ? atoi(e) : 1; }();
     const int grid = (vblocks < cus || !persist) ? vblocks : cus * (persist > 1 ? persist : 1) / (persist > 1 ? 2 : 1);
-    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
+    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -452,4 +491,28 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
+}
+
+// Transposed form (CT): fused ConvTranspose2d(k3,s2,p1,op1) launch (phase_cout > 0, weights of Op::ctf), 64 or 128 channels per
+// phase, enough patches to fill the chip, at most 15 % padding waste; with statistics whole 16x16 patches; a folded InstanceNorm
+// needs 128 <= Cin <= 256 (table slots, staged one chunk ahead).
+bool gdt_conv_halo_ct_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_CT"); return e ? atoi(e) : 1; }();   // 0 off
+    if (mode == 0 || !d.phase_cout || !d.w_frag || !d.out || d.out_f32 || d.res || d.in_out) return false;
+    if ((d.phase_cout != 64 && d.phase_cout != 128) || d.Cout != 4 * d.phase_cout || d.CoutPad != d.Cout || d.Cin % 64 != 0) return false;
+    if (d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.pad_reflect) return false;
+    if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
+    if (d.in_res && !d.in_norm) return false;
+    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * d.phase_cout >= (1L << 32)) return false;
+    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
+    const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
+    return tiles * (d.CoutPad / 256) >= 512 && useful >= 0.85;
+}
+
+int gdt_launch_conv_halo_ct(const ConvLaunch& d_in, hipStream_t stream) {
+    ConvLaunch d = d_in;
+    d.dbg = 0;
+    if (!d.in_norm) return launch_rb<256, 2, 4, 0, true>(d, stream);
+    return d.in_res ? launch_rb<256, 2, 4, 3, true>(d, stream) : launch_rb<256, 2, 4, 1, true>(d, stream);
 }

@@ -95,6 +95,8 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip (weights streamed into registers)
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_halo_ct_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip, transposed form (variant 960256)
+int gdt_launch_conv_halo_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* variant);
 // fused transposed conv (phase_cout > 0): GEMM column c -> (sub-pixel phase, output channel).  Each 64-column wave slice pairs

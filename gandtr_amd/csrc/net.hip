@@ -233,14 +233,14 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         bool want = ctf_mode == 2;
         if (ctf_mode == 1) {                      // is the input an InstanceNorm (without residual) consumed only here?
             for (int j = 0; j < i; ++j)
-                if (ops[j].kind == OP_INORM && ops[j].out == o.in && ops[j].res < 0) {
+                if (ops[j].kind == OP_INORM && ops[j].out == o.in) {
                     int uses = 0;
                     for (int k = 0; k < nops; ++k) uses += (ops[k].in == o.in) + (ops[k].res == o.in);
                     ConvLaunch dn = d; dn.in_norm = (const float*)net;
-                    want = uses == 1 && gdt_conv_igemm_rb_eligible(dn);
+                    want = uses == 1 && (gdt_conv_igemm_rb_eligible(dn) || gdt_conv_halo_ct_eligible(dn));
                 }
         }
-        if (want && gdt_conv_igemm_rb_eligible(d)) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = d.CoutPad / 256; }
+        if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = d.CoutPad / 256; }
     }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
@@ -278,7 +278,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             ctf_geometry(net, ok, N, T[ok.in], d);
             d.w_frag = (const f16*)net; d.out = (f16*)net;
             d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
-            if (!wb && irb_norm_ok(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            // (a residual without further consumers needs no write-back: the LDS-resident form adds it while staging)
+            ConvLaunch dn = d; dn.in_norm = (const float*)net; dn.in_res = oj.res >= 0 ? (const f16*)net : nullptr;
+            const bool ok_fold = consumers[oj.out] == 1 && (gdt_conv_halo_ct_eligible(dn) || (oj.res < 0 && gdt_conv_igemm_rb_eligible(dn)));
+            if (ok_fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
             continue;
         }
         conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
@@ -302,10 +305,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const int in = o.kind == OP_CONV ? conv_input(i) : o.in;
         if (in >= 0) T[in].last_use = i;
         if (o.res >= 0) T[o.res].last_use = i;
-        if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0 && plan.steps[plan.steps[i].norm_from].wb) {
-            const Op& nj = ops[plan.steps[i].norm_from];          // the conv reads the residual and writes the norm's output tensor
+        if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0) {
+            const Op& nj = ops[plan.steps[i].norm_from];          // the conv reads the residual and (wb) writes the norm's output tensor
             if (nj.res >= 0) T[nj.res].last_use = std::max(T[nj.res].last_use, i);
-            T[nj.out].last_use = std::max(T[nj.out].last_use, i);
+            if (plan.steps[plan.steps[i].norm_from].wb) T[nj.out].last_use = std::max(T[nj.out].last_use, i);
         }
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) T[o.feats[k]].last_use = i;
     }
@@ -855,7 +858,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.in = tptr(nj.in);
                     d.in_norm = (const float*)(ws + plan.steps[stp.norm_from].aux_off[1]);
                     d.in_relu = nj.relu;
-                    if (plan.steps[stp.norm_from].wb) { d.in_res = nj.res >= 0 ? tptr(nj.res) : nullptr; d.in_out = tptr(nj.out); }
+                    if (nj.res >= 0) d.in_res = tptr(nj.res);
+                    if (plan.steps[stp.norm_from].wb) d.in_out = tptr(nj.out);
                 }
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
@@ -866,8 +870,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.out = tptr(o.out); d.out_f32 = nullptr;
                     d.w = nullptr; d.w_lo = nullptr; d.w_frag = (const f16*)(net->dev_blob + o.ctf.w_frag_off);
                     d.stats_tile_base = 0;
-                    int variant = 0;
-                    rc = gdt_launch_conv_igemm_rb(d, st, &variant);
+                    int variant = 960256;
+                    rc = gdt_conv_halo_ct_eligible(d) ? gdt_launch_conv_halo_ct(d, st) : gdt_launch_conv_igemm_rb(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     break;
                 }

@@ -163,7 +163,7 @@ def test_image_stem_kernels(cuda_device, cfg):
         assert _rel(outs[tap_n].cpu(), F.relu(F.instance_norm(got, eps=1e-5))) < 2e-3
 
 
-@pytest.mark.parametrize("cin,cout,fold", [(128, 64, True), (256, 128, False), (128, 64, False)])
+@pytest.mark.parametrize("cin,cout,fold", [(128, 64, True), (256, 128, False), (128, 64, False), (256, 128, True), (256, 128, "res")])
 def test_transposed_conv_fused_phases(cuda_device, cin, cout, fold):
     """ConvTranspose2d(k3, s2, p1, op1) (p2p_networks.py:289-300) as ONE GEMM over the four sub-pixel phases
     (conv_igemm_rb.hip, phase_cout): plain, with the InstanceNorm statistics of its output taken in the epilogue, and with
@@ -173,7 +173,12 @@ def test_transposed_conv_fused_phases(cuda_device, cin, cout, fold):
     t = net.input(3)
     a = net.conv(t, synth._normal(0, "w0", (cin, 3, 3, 3), 0.4), pad=1, reflect=True)
     tap_in = net.output_nchw(a)
-    u = net.instance_norm(a, relu=True) if fold else a
+    if fold == "res":          # y = r + IN(a) feeding only the transposed conv (last ResnetBlock -> first up-sampling conv)
+        r = net.conv(t, synth._normal(0, "w1", (cin, 3, 3, 3), 0.4), pad=1, reflect=True)
+        tap_r = net.output_nchw(r)
+        u = net.instance_norm(a, relu=False, residual=r)
+    else:
+        u = net.instance_norm(a, relu=True) if fold else a
     wt, b = synth._normal(0, "wt", (cin, cout, 3, 3), math.sqrt(2.0 / (cin * 2.25))), synth._normal(0, "bt", (cout,), 0.2)
     o = net.conv(u, wt, b, stride=2, pad=1, transposed=True)
     tap = net.output_nchw(o)
@@ -182,7 +187,9 @@ def test_transposed_conv_fused_phases(cuda_device, cin, cout, fold):
     x = synth.synth_input(6, (32, 3, 64, 64))          # 512 tiles of 256 GEMM rows: the persistent kernel is eligible
     outs = net.forward(x.to(cuda_device))
     xin = outs[tap_in].cpu()
-    if fold:
+    if fold == "res":
+        xin = (outs[tap_r].cpu() + F.instance_norm(xin, eps=1e-5)).half().float()
+    elif fold:
         xin = F.relu(F.instance_norm(xin, eps=1e-5)).half().float()
     ref = F.conv_transpose2d(xin, wt.half().float(), b, stride=2, padding=1, output_padding=1)
     got = outs[tap].cpu()
