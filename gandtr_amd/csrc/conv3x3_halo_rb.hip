@@ -481,6 +481,7 @@ bool gdt_conv_halo_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_RB"); return e ? atoi(e) : 1; }();   // 0 off
     if (mode == 0 || !d.w_frag || d.CoutPad % 256 != 0) return false;
     if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;    // 32-bit element offsets
     return gdt_conv_halo_eligible(d);
 }
 
