@@ -26,7 +26,7 @@ def short(name):
     if base in ("conv3x3_halo_kernel", "conv3x3_halo_x3_kernel"):
         return "%s<%s>" % (base, a[1])
     if base == "conv3x3_halo_rb_kernel":
-        return "%s<%s>[mode %s]" % (base, a[0], a[3])
+        return "%s<%s>%s[mode %s]" % (base, a[0], "[transposed]" if len(a) > 4 and a[4] == "true" else "", a[3])
     if base == "conv_stem_kernel":
         return "%s<%d taps>" % (base, int(a[0]) ** 2)
     if base == "conv_igemm_rb_kernel":
@@ -65,7 +65,7 @@ def main():
     # bench.py names: the dominant kernel is reported without the mode suffix -> add the launch-weighted union
     groups = collections.defaultdict(list)
     for k in out["kernels"]:
-        groups[re.sub(r"\[.*\]$", "", k)].append(k)
+        groups[re.sub(r"\[(mode \d+|norm)\]$", "", k)].append(k)
     for base, ks in groups.items():
         if base in out["kernels"] and len(ks) == 1:
             continue
