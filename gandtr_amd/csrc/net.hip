@@ -228,10 +228,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         ctf_geometry(net, o, N, T[o.in], d);
         d.w_frag = (const f16*)net; d.out = (f16*)net;                                 // non-null markers only
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
-        // GDT_CONV_CTF: 0 never, 1 (default) only where it lets the producer's InstanceNorm be folded in, 2 whenever eligible
+        // GDT_CONV_CTF: 0 never, 1 (default) the LDS-resident kernel whenever eligible and the generic persistent GEMM only where
+        // it lets the producer's InstanceNorm be folded in, 2 whenever eligible
         static const int ctf_mode = [] { const char* e = getenv("GDT_CONV_CTF"); return e ? atoi(e) : 1; }();
-        bool want = ctf_mode == 2;
-        if (ctf_mode == 1) {                      // is the input an InstanceNorm (without residual) consumed only here?
+        bool want = ctf_mode == 2 || (ctf_mode == 1 && gdt_conv_halo_ct_eligible(d));       // the LDS-resident form always pays
+        if (ctf_mode == 1 && !want) {                      // is the input an InstanceNorm (without residual) consumed only here?
             for (int j = 0; j < i; ++j)
                 if (ops[j].kind == OP_INORM && ops[j].out == o.in) {
                     int uses = 0;

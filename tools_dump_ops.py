@@ -12,6 +12,8 @@ if which == "gen":
     net = engine.build_generator(synth.generator_state(0, "instance"), dev, precision=prec); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
 elif which == "genbn":
     net = engine.build_generator(synth.generator_state(0, "batch"), dev, precision=prec); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
+elif which == "hed":
+    net = engine.build_hed(synth.hed_state(0), dev, perm=[2, 1, 0], in_affine=([0.5] * 3, [0.09212946, 0.04247542, 0.01890622])); x = synth.synth_input(1, (64, 3, 256, 256), 1.0).to(dev)
 elif which == "r101":
     net = engine.build_embedder(synth.resnet101_state(0), dev, precision=prec); x = synth.synth_input(1, (32, 3, 1024, 1024)).to(dev)
 else:
