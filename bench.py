@@ -184,9 +184,24 @@ def main():
     gen = engine.build_generator(gsd, dev)
     xg = synth.synth_input(1000 + rank, (a.gen_batch, 3, 256, 256), 1.0).to(dev)
     dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
+    mfma_only = None
+    if rank == 0:          # sustained rate of the matrix pipe alone on this very device, measured right after the timed region
+        try:
+            import ctypes
+            from gandtr_amd import _hip
+            v = ctypes.c_double(0.0)
+            _hip.check(_hip.load().gdt_mfma_only_tflops(40, ctypes.byref(v), None))
+            mfma_only = round(v.value, 1)
+        except Exception as exc:                       # measurement aid only
+            print("mfma-only measurement failed: %r" % (exc,), file=sys.stderr)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
     roof = conv_roofline(gen, xg, traffic_key="r01_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    if roof is not None and mfma_only:
+        # context for `frac`: what the matrix pipe alone sustains on this device (power-limited clock), and the dominant
+        # kernel against that
+        roof["mfma_only_sustained"] = mfma_only
+        roof["frac_of_mfma_only"] = round(roof["achieved"] / mfma_only, 4)
     gen_tflops = gen_ips * GEN_GFLOP_PER_IMAGE / 1e3 / world
     del gen
     torch.cuda.empty_cache()

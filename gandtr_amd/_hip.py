@@ -53,6 +53,7 @@ SIGNATURES = {
     "gdt_retrieval_scores_ranks": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                            c_void_p]),
     "gdt_l2n_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "gdt_mfma_only_tflops": (c_int, [c_int, POINTER(c_double), c_void_p]),
 }
 
 

@@ -579,3 +579,57 @@ int gdt_k_hed_fuse(const float* const* score, const int* h, const int* w, const 
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ measurement aid
+namespace {
+__global__ __launch_bounds__(512) void mfma_only_kernel(const f16* __restrict__ src, float* __restrict__ out, int iters) {
+    f16x8 a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *(const f16x8*)(src + (threadIdx.x * 4 + i) * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = *(const f16x8*)(src + 16384 + (threadIdx.x * 2 + i) * 8);
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[i & 1], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][7];
+    if (s == 1234.5f) out[0] = s;
+}
+}  // namespace
+
+extern "C" int gdt_mfma_only_tflops(int millis, double* tflops, void* stream) {
+    GDT_REQUIRE(tflops && millis > 0 && millis <= 1000, "gdt_mfma_only_tflops(millis in 1..1000, tflops)");
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    GDT_CHECK_HIP(hipGetDevice(&dev));
+    GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    f16* src = nullptr; float* out = nullptr;
+    GDT_CHECK_HIP(hipMalloc((void**)&src, 65536 * sizeof(f16)));
+    GDT_CHECK_HIP(hipMalloc((void**)&out, 64));
+    std::vector<f16> h(65536);
+    unsigned x = 12345;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (f16)(((x >> 8) & 0xffff) / 65536.f - 0.5f); }
+    GDT_CHECK_HIP(hipMemcpyAsync(src, h.data(), h.size() * sizeof(f16), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    GDT_CHECK_HIP(hipEventCreate(&e0)); GDT_CHECK_HIP(hipEventCreate(&e1));
+    // 8 MFMAs x 32 cycles x 2 waves per SIMD per iteration: ~20 000 iterations are ~7 ms at 1.5 GHz; warm up, then time
+    const int per_launch = 20000, launches = millis / 7 + 1;
+    hipLaunchKernelGGL(mfma_only_kernel, dim3(cus), dim3(512), 0, st, src, out, per_launch);
+    GDT_CHECK_HIP(hipEventRecord(e0, st));
+    for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(mfma_only_kernel, dim3(cus), dim3(512), 0, st, src, out, per_launch);
+    GDT_CHECK_HIP(hipEventRecord(e1, st));
+    GDT_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GDT_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = (double)cus * 8 * per_launch * 8 * 2.0 * 32 * 32 * 16 * launches / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(out);
+    return GDT_OK;
+}

@@ -154,6 +154,14 @@ int gdt_retrieval_workspace_bytes(int ndb, int nq, int d, int with_ranks, size_t
 int gdt_retrieval_scores_ranks(const float* vecs, const float* qvecs, float* scores_t, int* ranks_t, int ndb, int nq, int d,
                                int index_base, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): sustained rate of the matrix pipe alone on this device -- a kernel of nothing
+ * but v_mfma_f32_32x32x16_f16 on random fp16 operands (8 independent accumulators per wave, 8 waves per CU) run for about
+ * `millis` milliseconds.  bench.py reports it next to the 2.5 PFLOP/s datasheet peak: these boxes throttle to 1.5-1.7 PFLOP/s
+ * under sustained matrix load (profiles/experiments/mfma_peak.hip is the stand-alone version).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int gdt_mfma_only_tflops(int millis, double* tflops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
