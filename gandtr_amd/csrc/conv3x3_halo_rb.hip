@@ -342,6 +342,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
                         }
                     }
                 __syncthreads();
+                if (!CT && d.pool2) {
+                    // fused MaxPool2d(2, 2) (VGG16 stages, imageretrievalnet.py:185-190): the half region holds, per wave row, four
+                    // complete patch rows = two pooled rows of 8 pixels; 2 x 2 x 8 pooled pixels x 32 channel groups per half
+#pragma unroll
+                    for (int it = 0; it < (2 * 16 * CPR) / NT; ++it) {
+                        const int id = it * NT + tid_e;
+                        const int chunk = id % CPR, pp = id / CPR;
+                        const int wq = pp >> 4, pr = (pp >> 3) & 1, pc = pp & 7;
+                        const f16* r0 = Ct + (wq * (WTM / 2) + pr * 32 + 2 * pc) * CP + chunk * 8;
+                        f16x8 v = __builtin_elementwise_max(*(const f16x8*)r0, *(const f16x8*)(r0 + CP));
+                        v = __builtin_elementwise_max(v, __builtin_elementwise_max(*(const f16x8*)(r0 + 16 * CP), *(const f16x8*)(r0 + 17 * CP)));
+                        const int y = cur.y0 + wq * 8 + p * 4 + 2 * pr, x = cur.x0 + 2 * pc, col = cur.tile_n * BN + chunk * 8;
+                        if ((y < d.H) & (x < d.W) & (col < d.Cout))
+                            *(f16x8*)(d.out + ((long)((cur.n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
+                    }
+                    continue;
+                }
                 constexpr int QB = NCH / 2;                     // residual loads in flight per thread
 #pragma unroll
                 for (int qb = 0; qb < NCH; qb += QB) {

@@ -62,6 +62,25 @@ __device__ __forceinline__ void conv_epilogue_f16(const ConvLaunch& d, const f32
     }
     if (d.dbg & 8) return;                  // timing-only ablation: no global stores
     constexpr int CPR = BN / 8;             // 16-byte chunks per tile row
+    if (d.pool2) {
+        // fused MaxPool2d(2, 2) (patch kernels only: tile row = py * 16 + px): one pooled pixel = max over rows r, r+1, r+16, r+17
+        for (int id = tid; id < (BM / 4) * CPR; id += NT) {
+            const int chunk = id % CPR, pp = id / CPR;
+            const int pr = pp >> 3, pc = pp & 7, row0 = pr * 32 + 2 * pc;
+            const f16* r0 = Ct + row0 * CP + chunk * 8;
+            f16x8 v = __builtin_elementwise_max(*(const f16x8*)r0, *(const f16x8*)(r0 + CP));
+            v = __builtin_elementwise_max(v, __builtin_elementwise_max(*(const f16x8*)(r0 + 16 * CP), *(const f16x8*)(r0 + 17 * CP)));
+            bool ok;
+            const long pix = pixel_of(row0, ok);                      // (n * H + y) * W + x of the window's top-left pixel
+            const int col = tile_n * BN + chunk * 8;
+            if (ok && col < d.Cout) {
+                const long q = pix / d.W; const int x = (int)(pix - q * d.W);
+                const long n = q / d.H; const int y = (int)(q - n * d.H);
+                *(f16x8*)(d.out + (((n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
+            }
+        }
+        return;
+    }
     constexpr int NCH = BM * CPR / NT;      // chunks per thread
     // All residual loads are issued first (the accumulators are dead by now, so registers are plentiful) and consumed
     // afterwards.  With the load inside the per-chunk branch each lane had ONE residual load in flight and the read ran at

@@ -298,6 +298,14 @@ bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d) {
     return d.Cin == 64 && (d.OHg * d.OWg) % 256 == 0 && d.M % 256 == 0;
 }
 
+// A fused 2x2 max pool needs a patch kernel (16x16 patches: conv3x3_halo_rb.hip / conv3x3_halo.hip), even H and W, and a plain
+// epilogue (no statistics, residual or write-back).
+bool gdt_conv_pool2_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_POOL"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || (d.H & 1) || (d.W & 1) || d.stats || d.res || d.in_out || d.out_f32 || d.phase_cout) return false;
+    return gdt_conv_halo_rb_eligible(d) || gdt_conv_halo_eligible(d);
+}
+
 int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
 int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
@@ -315,6 +323,7 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
                              "fused InstanceNorm statistics need whole 128-row tiles per image and a plain conv epilogue");
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
+    if (d.pool2) GDT_REQUIRE(gdt_conv_halo_rb_eligible(d) || gdt_conv_halo_eligible(d), "fused max pool needs a patch kernel");
     if (gdt_conv_stem_eligible(d)) { *variant = 950000 + d.ntaps; return gdt_launch_conv_stem(d, stream); }
     if (!gdt_conv_halo_rb_eligible(d) && !gdt_conv_halo_eligible(d) && gdt_conv_igemm_rb_eligible(d)) return gdt_launch_conv_igemm_rb(d, stream, variant);
     if (d.in_norm && !gdt_conv_halo_eligible(d))

@@ -204,7 +204,7 @@ int launch_stem(const ConvLaunch& d, hipStream_t stream) {
 // fused statistics need whole 128-pixel records per wave: stride 1 and OW % 32 == 0, OH % 16 == 0.
 bool gdt_conv_stem_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_STEM"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || !d.w_frag || d.Cin != 8 || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm) return false;
+    if (mode == 0 || !d.w_frag || d.Cin != 8 || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm || d.pool2) return false;
     if (d.sy != d.sx || d.dys != 1 || d.dxs != 1 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
     const bool k7 = d.ntaps == 49 && d.TW == 7 && d.dy0 == -3 && d.dx0 == -3 && (d.sy == 1 || d.sy == 2);
     const bool k3 = d.ntaps == 9 && d.TW == 3 && d.dy0 == -1 && d.dx0 == -1 && d.sy == 1;

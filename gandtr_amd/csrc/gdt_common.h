@@ -69,6 +69,7 @@ struct ConvLaunch {
     int dbg;                      // timing-only ablation knob (env GDT_CONV_DBG): 1 skip staging loads, 2 skip MFMAs
     unsigned long long* stamp_out;  // diagnostic builds only (GDT_CONV_STAMP): per-wave s_memtime totals
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
+    int pool2;                    // 1: MaxPool2d(2, 2) fused into the epilogue of the patch kernels; `out` is the pooled [N][H/2][W/2][Cout] tensor
     int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
                                   //      written to output pixel (2y + py, 2x + px); Cout / CoutPad count GEMM columns (conv_igemm_rb.hip)
 };
@@ -95,6 +96,7 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip (weights streamed into registers)
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_pool2_eligible(const ConvLaunch& d);         // conv_igemm.hip: can this launch (pool2 = 0) take a fused 2x2 max pool?
 bool gdt_conv_halo_ct_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip, transposed form (variant 960256)
 int gdt_launch_conv_halo_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)

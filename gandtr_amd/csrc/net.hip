@@ -141,6 +141,8 @@ struct Step {
     int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
     bool wb;         // INORM folded into a conv that also writes the normalised tensor out (residual / further consumers)
     bool ctf;        // CONV (transposed): runs as the single fused-phase launch
+    int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
+    bool skip;       // MAXPOOL fused into its producer
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
@@ -189,7 +191,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].stats_sets = 1; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -299,6 +301,22 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         if (plan_dbg) fprintf(stderr, "[plan] inorm %d -> conv %d: Cin %d s%d k%d rowsplit %d fold %d\n", j, k, d.Cin, ok.cd.stride, ok.cd.kh, (int)ok.rowsplit, (int)fold);
     }
 
+    // ---- pass 2b: MaxPool2d(2, 2) fused into the epilogue of its producer (VGG16 stages): conv -> pool with no other consumer
+    for (int j = 0; j < nops; ++j) {
+        const Op& oj = ops[j];
+        if (oj.kind != OP_MAXPOOL || oj.k != 2 || oj.s != 2 || oj.p != 0 || net->precision || consumers[oj.in] != 1) continue;
+        int i = -1;
+        for (int k = 0; k < j; ++k) if (ops[k].kind == OP_CONV && ops[k].out == oj.in) i = k;
+        if (i < 0 || ops[i].cd.transposed || ops[i].cd.out_f32_nchw || ops[i].res >= 0) continue;
+        ConvLaunch d{};
+        conv_geometry(net, ops[i], ops[i].phases[0], N, T[ops[i].in], d);
+        d.w_frag = ops[i].phases[0].has_frag ? (const f16*)net : nullptr; d.out = (f16*)net;            // non-null markers only
+        d.in_norm = plan.steps[i].norm_from >= 0 ? (const float*)net : nullptr;
+        d.stats = conv_fuses_stats(ops[i], T[ops[i].in]) ? (float*)net : nullptr;
+        if (plan.steps[i].norm_from >= 0 && plan.steps[plan.steps[i].norm_from].wb) continue;
+        if (gdt_conv_pool2_eligible(d)) { plan.steps[i].pool_into = j; plan.steps[j].skip = true; }
+    }
+
     // ---- pass 3: liveness + first-fit layout
     auto conv_input = [&](int i) { return plan.steps[i].norm_from >= 0 ? ops[plan.steps[i].norm_from].in : ops[i].in; };
     for (int i = 0; i < nops; ++i) {
@@ -329,7 +347,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             case OP_CONV: {
                 const Tensor& ti = T[o.in];       // same size as the raw tensor when the norm is folded
                 const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh);
-                if (o.out >= 0) alloc_out();
+                if (st.pool_into >= 0) {                      // the conv writes the pooled tensor; its own output never exists
+                    Tensor& t = T[ops[st.pool_into].out];
+                    t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
+                    t.off = arena.alloc(t.bytes);
+                } else if (o.out >= 0) alloc_out();
                 if (o.rowsplit) {
                     const size_t b = (size_t)N * oh * ti.W * o.rs_cout8 * net->esize();
                     st.aux_off[1] = arena.alloc(b);
@@ -364,7 +386,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 else arena.release(st.aux_off[1], mr_bytes);
                 break;
             }
-            case OP_MAXPOOL: alloc_out(); break;
+            case OP_MAXPOOL: if (!st.skip) alloc_out(); break;
             case OP_GEM: {
                 const Tensor& ti = T[o.in];
                 st.aux_off[0] = arena.alloc((size_t)N * ti.C * sizeof(float));
@@ -883,6 +905,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
                     if (o.rowsplit) { d.out = (f16*)(ws + stp.aux_off[1]); d.out_f32 = nullptr; d.Cout = o.rs_cout8; d.bias = nullptr; }
                     else if (o.cd.out_f32_nchw) { d.out = nullptr; d.out_f32 = (float*)outputs[o.slot]; }
+                    else if (stp.pool_into >= 0) { d.out = tptr(net->ops[stp.pool_into].out); d.out_f32 = nullptr; d.pool2 = 1; }
                     else { d.out = tptr(o.out); d.out_f32 = nullptr; }
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
                     d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
@@ -928,6 +951,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 break;
             }
             case OP_MAXPOOL: {
+                if (stp.skip) break;                  // done by the producing conv's epilogue
                 const Tensor& ti = T[o.in]; const Tensor& to = T[o.out];
                 rc = gdt_k_maxpool(tptr(o.in), tptr(o.out), f32, n, ti.H, ti.W, ti.C, to.H, to.W, o.k, o.s, o.p, st);
                 break;

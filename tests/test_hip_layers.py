@@ -90,6 +90,28 @@ def test_conv3x3_persistent_halo_kernel(cuda_device, cfg):
     assert _rel(got, ref) < (4e-3 if bn else 2e-3), (cfg, _rel(got, ref))
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(256, 256, (8, 128, 128)), (64, 64, (8, 128, 128)), (128, 128, (9, 60, 128)), (256, 512, (8, 96, 96))])
+def test_conv_relu_maxpool_fused(cuda_device, cin, cout, shape):
+    """VGG16 stage ends (Conv2d 3x3 + ReLU + MaxPool2d(2, 2), torchvision cfg "D"): the pool runs in the conv epilogue of the
+    patch kernels (conv3x3_halo_rb.hip / conv_epilogue.h) and the full-resolution tensor is never written."""
+    from gandtr_amd.engine import HipNet
+    n, h, w = shape
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "w0", (cin, 3, 1, 1), 0.7))
+    tap_in = net.output_nchw(a)
+    wt, b = synth._normal(0, "w", (cout, cin, 3, 3), math.sqrt(2.0 / (cin * 9))), synth._normal(0, "b", (cout,), 0.2)
+    o = net.maxpool(net.conv(a, wt, b, pad=1, relu=True), 2, 2)
+    tap = net.output_nchw(o)
+    net.finalize()
+    x = synth.synth_input(7, (n, 3, h, w))
+    outs = net.forward(x.to(cuda_device))
+    ref = F.max_pool2d(F.relu(F.conv2d(outs[tap_in].cpu(), wt.half().float(), b, padding=1)), 2, 2)
+    got = outs[tap].cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 2e-3
+
+
 def test_conv_ragged_tail(cuda_device):
     """M not a multiple of the 128-row tile and odd spatial sizes."""
     got, ref = _run_single_conv(cuda_device, 64, 64, 3, 1, 1, True, False, True, False, n=3, h=13, w=17)
