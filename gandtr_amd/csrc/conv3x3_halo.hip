@@ -312,7 +312,8 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d) {
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
     // padded patches waste work on ragged sizes: require >= 85 % useful pixels
     const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
-    return tiles * (d.CoutPad / bn) >= 512 && useful >= 0.85;
+    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();   // (batch-1 sweeps: 64-128 best; 512 loses 25 % on a 1024^2 image)
+    return tiles * (d.CoutPad / bn) >= min_tiles && useful >= 0.85;
 }
 
 int gdt_launch_conv_halo(const ConvLaunch& d_in, hipStream_t stream) {

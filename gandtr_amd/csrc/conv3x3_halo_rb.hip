@@ -525,7 +525,8 @@ bool gdt_conv_halo_ct_eligible(const ConvLaunch& d) {
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * d.phase_cout >= (1L << 32)) return false;
     const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
     const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
-    return tiles * (d.CoutPad / 256) >= 512 && useful >= 0.85;
+    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();   // (batch-1 sweeps: 64-128 best; 512 loses 25 % on a 1024^2 image)
+    return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
 }
 
 int gdt_launch_conv_halo_ct(const ConvLaunch& d_in, hipStream_t stream) {
