@@ -32,6 +32,14 @@ def test_generator_64x256_batch_independence_and_determinism(cuda_device, precis
     assert float((single - full[5:6]).abs().max() / full.abs().max()) < tol
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(cuda_device)
     assert torch.equal(net.forward(x[perm])[net.out_slot], full[perm])   # images are independent units
+    # the production geometry itself (batch 64: persistent halo / transposed / stem / head kernels, every InstanceNorm folded)
+    # against the CPU oracle on two of its images -- same gates as test_hip_models.py (fp16 envelope / 1e-3 in f16x3)
+    from oracle import gandtr_oracle as O
+    sd = synth.generator_state(0, "instance")
+    for i in (5, n - 1):
+        ref = O.resnet_generator(x[i:i + 1].cpu(), sd, "instance", 9, pre_tanh=True)
+        err = float((full[i:i + 1].cpu() - ref).abs().max() / ref.abs().max())
+        assert err < (3.5e-3 if precision == "f16" else 1e-3), (i, err)
 
 
 def test_hedngan_64x256_with_hed(cuda_device):
@@ -57,6 +65,12 @@ def test_embedder_1024_properties(cuda_device, arch, n):
     shards = torch.cat([net.forward(x[: n // 2])[net.out_slot], net.forward(x[n // 2:])[net.out_slot]])
     cos = torch.nn.functional.cosine_similarity(shards, d, dim=1)
     assert float(cos.min()) > 0.99999                                  # rank shards concatenated == whole batch
+    # the full-size geometry (patch kernels, fused max pools, stem kernel) against the CPU oracle on one image: north_star gates
+    from oracle import gandtr_oracle as O
+    ref = O.image_retrieval_forward(x[1:2].cpu(), sd, arch).t().contiguous()[0]
+    got = d[1].cpu()
+    assert float(torch.nn.functional.cosine_similarity(got, ref, dim=0)) >= 0.9999
+    assert float((got - ref).abs().max()) <= 1e-3
     # hub-default pyramid {1, 1/sqrt2, 1/2} -> 1024, 724, 512 inside the pack kernel; aggregate; whiten with the identity
     scales = [1.0, 2 ** -0.5, 0.5]
     per_scale = torch.stack([net.forward(x[:2], scale=s)[net.out_slot] for s in scales])
