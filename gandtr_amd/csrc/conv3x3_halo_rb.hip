@@ -35,7 +35,7 @@ constexpr int A_BYTES = HALO_ROWS_PAD * ROWB;
 constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
 constexpr int BM = PH * 16;
 
-constexpr int C_OFF = 2 * A_BYTES + NORM_BYTES;            // epilogue transpose region (half a C tile), disjoint from the halo stages
+constexpr int C_OFF = 2 * A_BYTES + NORM_BYTES;            // epilogue transpose patches (one per wave), disjoint from the halo stages
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned norm_res_pair(unsigned raw, unsigned res, fl
 }
 
 template <int BN>
-constexpr size_t rb_lds_bytes() { return (size_t)C_OFF + (size_t)(BM / 2) * (BN + 8) * 2; }
+constexpr size_t rb_lds_bytes() { return (size_t)C_OFF + (size_t)8 * 32 * (BN / 4 + 8) * 2; }      // + eight wave-private transpose patches
 
 struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 
@@ -301,152 +301,112 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             }
         }
 
-        // ------------------------------------------------------------ epilogue: bias, ReLU, fp16, LDS transpose in two
-        // halves (row blocks {0,1} then {2,3} of every wave) through a region of its own, InstanceNorm statistics records,
-        // residual.  Its first barrier is also the chunk barrier that publishes the next tile's first halo stage.
+        // ------------------------------------------------------------ tile end.  One barrier, as at every chunk end: all waves
+        // are done with the last halo stage, and the next tile's first stage (written during the last chunk) is visible.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ------------------------------------------------------------ epilogue, WAVE-PRIVATE: no workgroup barrier in it, so a
+        // wave runs through it and on into the next tile on its own.  MFMA operands are swapped (D = W * A^T): lane (fr, fh)
+        // holds pixel fr of row block i and, in registers 4g .. 4g+3, the four consecutive output channels 8g + 4fh .. +3 of
+        // column block j.  Per 32-pixel row block (= two patch rows) the wave transposes its 32 x 64 slice through a private
+        // 4.6 KB LDS patch (8-byte writes, 16-byte reads) and stores one full 128-byte line per pixel; bias, ReLU, residual
+        // (+ReLU), fused MaxPool2d(2,2), sub-pixel scatter (CT) on the way.  InstanceNorm statistics: the wave's 128 rows are
+        // one record; each lane owns an 8-channel group, sums the fp16 values it stores, lanes sharing a group are merged by a
+        // fixed butterfly -- no cross-wave step (the four waves of a row write disjoint channel ranges of the record).
         if (!(d.dbg & 4)) {
-            if (nchunks == 1) __syncthreads();          // (no chunk barrier separates this tile from the previous epilogue's reads)
-            // MFMA operands are swapped (D = W * A^T): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3,
-            // the four consecutive output channels 8g + 4fh .. +3 of column block j -- 8-byte LDS writes (32 per lane and tile
-            // instead of 128 two-byte ones, see conv_igemm_rb.hip).  InstanceNorm statistics are taken in the store phase from
-            // the fp16 values that are written out (each thread owns one 8-channel group), merged in a fixed order.
-            constexpr int CP = BN + 8, HM = BM / 2, CPR = BN / 8, NCH = HM * CPR / NT;
-            f16* Ct = (f16*)(smem + C_OFF);
+            constexpr int PCP = WTN + 8;                                   // halves per patch row (64 + 8)
+            f16* patch = (f16*)(smem + C_OFF) + wave * (32 * PCP);
             const bool relu_now = d.relu && !d.res;
             const bool has_res = d.res != nullptr;
-            int fr_e = fr, fh_e = fh, tid_e = tid;              // (opaque copies: keeps the epilogue's addresses out of the
-            asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(tid_e));   //  persistent loop's invariant set, where they would spill)
-            float st1[2][8], st2[2][8];
+            int fr_e = fr, fh_e = fh, lane_e = lane;            // (opaque copies: keeps the epilogue's addresses out of the
+            asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(lane_e));  //  persistent loop's invariant set, where they would spill)
+            const int ch = lane_e & 7;                           // this lane's 8-channel group within the wave's 64 columns
+            const int col = cur.tile_n * BN + wn * WTN + ch * 8; // first GEMM column of the group
+            int ct_ph = 0, ct_co = 0;
+            if (CT) gdt_ctf_column(col, d.phase_cout, ct_ph, ct_co);
+            float st1[8], st2[8];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { st1[r][e] = 0.f; st2[r][e] = 0.f; }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (p == 1) __syncthreads();                   // the stores of the first half have read the region
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = wn * WTN + j * 32 + 8 * g + 4 * fh_e;
+                        const int c4 = j * 32 + 8 * g + 4 * fh_e;
                         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (d.bias) bv = *(const float4*)(d.bias + cur.tile_n * BN + col);
-#pragma unroll
-                        for (int ii = 0; ii < TM / 2; ++ii) {
-                            const int rr = wm * (WTM / 2) + ii * 32 + fr_e;
-                            const f32x16& a = acc[p * (TM / 2) + ii][j];
-                            float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
-                            if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
-                            *(f16x4*)(Ct + rr * CP + col) = h;
-                        }
+                        if (d.bias) bv = *(const float4*)(d.bias + cur.tile_n * BN + wn * WTN + c4);
+                        const f32x16& a = acc[i][j];
+                        float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
+                        if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
+                        *(f16x4*)(patch + fr_e * PCP + c4) = h;
                     }
-                __syncthreads();
+                const int prow = wm * (WTM / 16) + 2 * i;                  // first of the block's two patch rows
                 if (!CT && d.pool2) {
-                    // fused MaxPool2d(2, 2) (VGG16 stages, imageretrievalnet.py:185-190): the half region holds, per wave row, four
-                    // complete patch rows = two pooled rows of 8 pixels; 2 x 2 x 8 pooled pixels x 32 channel groups per half
-#pragma unroll
-                    for (int it = 0; it < (2 * 16 * CPR) / NT; ++it) {
-                        const int id = it * NT + tid_e;
-                        const int chunk = id % CPR, pp = id / CPR;
-                        const int wq = pp >> 4, pr = (pp >> 3) & 1, pc = pp & 7;
-                        const f16* r0 = Ct + (wq * (WTM / 2) + pr * 32 + 2 * pc) * CP + chunk * 8;
-                        f16x8 v = __builtin_elementwise_max(*(const f16x8*)r0, *(const f16x8*)(r0 + CP));
-                        v = __builtin_elementwise_max(v, __builtin_elementwise_max(*(const f16x8*)(r0 + 16 * CP), *(const f16x8*)(r0 + 17 * CP)));
-                        const int y = cur.y0 + wq * 8 + p * 4 + 2 * pr, x = cur.x0 + 2 * pc, col = cur.tile_n * BN + chunk * 8;
-                        if ((y < d.H) & (x < d.W) & (col < d.Cout))
-                            *(f16x8*)(d.out + ((long)((cur.n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
-                    }
+                    // fused MaxPool2d(2, 2): the block's two patch rows give one pooled row of 8 pixels x 8 channel groups
+                    const int pc = lane_e >> 3;
+                    const f16* r0 = patch + (2 * pc) * PCP + ch * 8;
+                    f16x8 v = __builtin_elementwise_max(*(const f16x8*)r0, *(const f16x8*)(r0 + PCP));
+                    v = __builtin_elementwise_max(v, __builtin_elementwise_max(*(const f16x8*)(r0 + 16 * PCP), *(const f16x8*)(r0 + 17 * PCP)));
+                    const int y = cur.y0 + prow, x = cur.x0 + 2 * pc;
+                    if ((y < d.H) & (x < d.W) & (col < d.Cout))
+                        *(f16x8*)(d.out + ((long)((cur.n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
                     continue;
                 }
-                constexpr int QB = NCH / 2;                     // residual loads in flight per thread
+                unsigned offs[4];
+                f16x8 rv[4];
+                unsigned okmask = 0;
 #pragma unroll
-                for (int qb = 0; qb < NCH; qb += QB) {
-                    unsigned offs[QB];
-                    f16x8 rv[QB];
-                    unsigned okmask = 0;
-#pragma unroll
-                    for (int q = 0; q < QB; ++q) {
-                        const int id = (qb + q) * NT + tid_e;
-                        const int rr = id / CPR;
-                        const int row = (rr / (WTM / 2)) * WTM + p * (WTM / 2) + (rr % (WTM / 2));
-                        const int col = cur.tile_n * BN + (id % CPR) * 8;
-                        const int y = cur.y0 + (row >> 4), x = cur.x0 + (row & 15);
-                        const bool ok = (y < d.H) & (x < d.W) & (col < d.Cout);
-                        if (!CT) {
-                            offs[q] = ok ? (unsigned)(((cur.n * d.H + y) * d.W + x) * d.Cout + col) : 0u;
-                        } else {                        // column block -> sub-pixel phase of the 2x up-sampled output
-                            int ph, co;
-                            gdt_ctf_column(col, d.phase_cout, ph, co);
-                            offs[q] = ok ? (unsigned)(((cur.n * d.OH + 2 * y + (ph >> 1)) * d.OW + 2 * x + (ph & 1)) * d.phase_cout + co) : 0u;
-                        }
-                        okmask |= (ok ? 1u : 0u) << q;
-                        if (has_res) rv[q] = *(const f16x8*)(d.res + offs[q]);    // offset 0 is a valid address for masked chunks
-                    }
-#pragma unroll
-                    for (int q = 0; q < QB; ++q) {
-                        const int id = (qb + q) * NT + tid_e;
-                        f16x8 v = *(const f16x8*)(Ct + (id / CPR) * CP + (id % CPR) * 8);
-                        if (d.stats) {
-                            const int rec = (qb + q) >= NCH / 2 ? 1 : 0;        // (compile-time after unrolling: region rows are wave-major)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; st1[rec][e] += f; st2[rec][e] += f * f; }
-                        }
-                        if (has_res) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                float t = (float)v[e] + (float)rv[q][e];
-                                if (d.relu) t = fmaxf(t, 0.f);
-                                v[e] = (f16)t;
-                            }
-                        }
-                        if ((okmask >> q) & 1u) *(f16x8*)(d.out + offs[q]) = v;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int px = (lane_e >> 3) + 8 * q;                // pixel of the block: patch row prow + (px >> 4), column px & 15
+                    const int y = cur.y0 + prow + (px >> 4), x = cur.x0 + (px & 15);
+                    const bool ok = (y < d.H) & (x < d.W) & (col < d.Cout);
+                    if (!CT) offs[q] = ok ? (unsigned)(((cur.n * d.H + y) * d.W + x) * d.Cout + col) : 0u;
+                    else offs[q] = ok ? (unsigned)(((cur.n * d.OH + 2 * y + (ct_ph >> 1)) * d.OW + 2 * x + (ct_ph & 1)) * d.phase_cout + ct_co) : 0u;
+                    okmask |= (ok ? 1u : 0u) << q;
+                    if (has_res) rv[q] = *(const f16x8*)(d.res + offs[q]);        // offset 0 is a valid address for masked pieces
                 }
-            }
-            if (d.stats) {      // one 128-row record per wave row: lanes sharing a channel group, then the 8 waves, fixed order
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    const int px = (lane_e >> 3) + 8 * q;
+                    f16x8 v = *(const f16x8*)(patch + px * PCP + ch * 8);
+                    if (d.stats && ((okmask >> q) & 1u)) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { st1[r][e] += __shfl_xor(st1[r][e], 32); st2[r][e] += __shfl_xor(st2[r][e], 32); }
-                __syncthreads();                                   // every read of the transpose region is done: reuse it
-                float* F = (float*)Ct;                             // [wave][record][BN][2]
-                if ((tid_e & 63) < CPR) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; st1[e] += f; st2[e] += f * f; }
+                    }
+                    if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            float* f = F + (((tid_e >> 6) * 2 + r) * BN + (tid_e & 63) * 8 + e) * 2;
-                            f[0] = st1[r][e]; f[1] = st2[r][e];
+                            float t = (float)v[e] + (float)rv[q][e];
+                            if (d.relu) t = fmaxf(t, 0.f);
+                            v[e] = (f16)t;
                         }
-                }
-                __syncthreads();
-                if (!CT && tid_e < BN * 2) {
-                    const int rec = tid_e / BN, col = tid_e % BN;
-                    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + col) * 2]; t2 += F[((w * 2 + rec) * BN + col) * 2 + 1]; }
-                    const int gcol = cur.tile_n * BN + col;
-                    if (gcol < d.Cout) {
-                        float* dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + rec) * 2) * d.Cout + gcol;
-                        dst[0] = t1; dst[d.Cout] = t2;
                     }
+                    if ((okmask >> q) & 1u) *(f16x8*)(d.out + offs[q]) = v;
                 }
-                if (CT && tid_e < d.phase_cout * 2) {
-                    // the sub-pixel phases held by this N tile are merged per channel; one record set per N tile (the
-                    // finalize kernel sums the sets like it sums the phase launches' sets)
-                    const int rec = tid_e / d.phase_cout, col = tid_e % d.phase_cout;
-                    float t1 = 0.f, t2 = 0.f;
-                    for (int blk = 0; blk < BN / 32; ++blk) {
-                        int ph, co;
-                        gdt_ctf_column(cur.tile_n * BN + blk * 32 + (col & 31), d.phase_cout, ph, co);
-                        if (co != col) continue;
-                        const int c2 = blk * 32 + (col & 31);
+            }
+            if (d.stats) {
 #pragma unroll
-                        for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + c2) * 2]; t2 += F[((w * 2 + rec) * BN + c2) * 2 + 1]; }
-                    }
-                    float* dst = d.stats + ((long)(cur.tile_n * (ntm * WGM) + cur.tile_m * WGM + rec) * 2) * d.phase_cout + col;
-                    dst[0] = t1; dst[d.phase_cout] = t2;
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
+                    if (CT) { st1[e] += __shfl_xor(st1[e], 4); st2[e] += __shfl_xor(st2[e], 4); }       // the wave's two sub-pixel phases of a channel
+                }
+                if (!CT && lane_e < 8 && col < d.Cout) {
+                    float* dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + col;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { dst[e] = st1[e]; dst[d.Cout + e] = st2[e]; }
+                }
+                if (CT && lane_e < 4) {
+                    // one record set per phase pair (gdt_ctf_column: pair 0 = phases 0 + 3, pair 1 = phases 1 + 2); the finalize
+                    // kernel sums the two sets
+                    const int pair = ((cur.tile_n * WGN + wn) / (d.phase_cout >> 5)) & 1;
+                    float* dst = d.stats + ((long)(pair * (ntm * WGM) + cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { dst[e] = st1[e]; dst[d.phase_cout + e] = st2[e]; }
                 }
             }
         } else {                         // ablation: no epilogue (keep the accumulators observable)
@@ -456,9 +416,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
 #pragma unroll
                 for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][15];
             if (sacc == 12345.678f) d.out[0] = (f16)sacc;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
         }
         if (!nxt.valid) break;
         cur = nxt; vb += gridDim.x; slot ^= 1;

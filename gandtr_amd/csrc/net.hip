@@ -243,7 +243,8 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                     want = uses == 1 && (gdt_conv_igemm_rb_eligible(dn) || gdt_conv_halo_ct_eligible(dn));
                 }
         }
-        if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = d.CoutPad / 256; }
+        // record sets the finalize kernel sums: the LDS-resident kernel writes one per phase pair, the generic one per N tile
+        if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = gdt_conv_halo_ct_eligible(d) ? 2 : d.CoutPad / 256; }
     }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
