@@ -329,6 +329,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             float st1[8], st2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+            float4 bvs[TN][4];                                   // bias of this lane's channels, fetched once per tile
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bvs[j][g] = d.bias ? *(const float4*)(d.bias + cur.tile_n * BN + wn * WTN + j * 32 + 8 * g + 4 * fh_e) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -336,8 +342,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c4 = j * 32 + 8 * g + 4 * fh_e;
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (d.bias) bv = *(const float4*)(d.bias + cur.tile_n * BN + wn * WTN + c4);
+                        const float4 bv = bvs[j][g];
                         const f32x16& a = acc[i][j];
                         float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
                         if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
