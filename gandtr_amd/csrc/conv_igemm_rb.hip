@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned norm_pair(unsigned raw, float s0, float h0, 
 template <int BN, int WGM>
 constexpr int irb_region_rows() { return (BM / WGM) / 32 >= 2 ? BM / 2 : BM; }
 template <int BN, int WGM>
-constexpr size_t irb_lds_bytes() { return (size_t)C_OFF + (size_t)irb_region_rows<BN, WGM>() * (BN + 8) * 2; }
+constexpr size_t irb_lds_bytes() { return (size_t)C_OFF + (size_t)8 * 32 * (64 + 8) * 2; }        // + eight wave-private transpose patches
 
 struct TileAt { int tile_m, tile_n; bool valid; };
 
@@ -265,158 +265,103 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
                 for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][15];
             if (sacc == 12345.678f) d.out[0] = (f16)sacc;
         } else {
-            // The MFMAs run with the operands swapped (D = W * A^T): lane (fr, fh) holds pixel fr of row block i and, in
-            // registers 4g .. 4g+3, the FOUR CONSECUTIVE output channels 8g + 4fh .. +3 of column block j.  The transpose
-            // through LDS therefore takes 8-byte writes -- 4 x TM x TN per lane instead of the 16 x TM x TN two-byte writes
-            // of the [pixel][cout] accumulator layout, which (with the barriers around them) cost more than the K-loop of a
-            // 1x1 conv: ResNet-101's 58 launches spent 7.0 of 12.2 ms in the epilogue, 3.7 ms of that without any global
-            // memory traffic.
-            constexpr int CP = BN + 8, CPR = BN / 8;
-            constexpr int HT = (TM + 1) / 2;                      // row blocks per wave and half (TM == 1: all in half 0)
-            constexpr int HROWS = TM >= 2 ? WTM / 2 : WTM;        // rows per wave and half
-            constexpr int NHALF = TM >= 2 ? 2 : 1;
-            constexpr int REG_ROWS = WGM * HROWS;                 // rows in the region per half (128, or 256 when TM == 1)
-            static_assert(REG_ROWS == irb_region_rows<BN, WGM>(), "epilogue region");
-            constexpr int NCHH = REG_ROWS * CPR / NT;
-            f16* Ct = (f16*)(smem + C_OFF);
+            // WAVE-PRIVATE epilogue (as conv3x3_halo_rb.hip): the MFMAs run with the operands swapped (D = W * A^T), so lane (fr, fh)
+            // holds pixel fr of row block i and, in registers 4g .. 4g+3, the four consecutive output channels 8g + 4fh .. +3 of
+            // column block j.  Per 32-row block the wave transposes its 32 x 64 slice through its own 4.6 KB LDS patch (8-byte
+            // writes, 16-byte reads) and stores one 128-byte line per pixel; bias, ReLU, residual (+ReLU), sub-pixel scatter
+            // (fused transposed conv) on the way.  No workgroup barrier.  InstanceNorm statistics: sums of the stored fp16 values
+            // over the wave's WTM rows, lanes sharing a channel group merged by a fixed butterfly, written as the wave's own
+            // record -- records of WTM < 128 rows go to separate record sets (gdt_conv_igemm_rb_stats_sets) the finalize sums.
+            constexpr int PCP = WTN + 8;
+            static_assert(WTN == 64, "wave tile width");
+            f16* patch = (f16*)(smem + C_OFF) + wave * (32 * PCP);
             const bool relu_now = d.relu && !d.res;
             const bool has_res = d.res != nullptr && !(d.dbg & 16);
             const bool dense = d.osy == 1 && d.osx == 1 && d.OHg == d.OH && d.OWg == d.OW;
-            // (opaque copies: the epilogue's lane-dependent addresses are invariant across the persistent tile loop, and
-            // hoisted out of it they are spilled -- 57 registers -- and reloaded one by one)
-            int fr_e = fr, fh_e = fh, tid_e = tid;
-            asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(tid_e));
-            // InstanceNorm partial statistics (layers followed by an InstanceNorm): accumulated in the store phase below from the
-            // fp16 values that are written out -- each thread owns one 8-channel group and 2 x NCHH / 2 rows of each 128-row
-            // record -- and merged across lanes / waves in a fixed order afterwards.
-            float st1[2][8], st2[2][8];
+            int fr_e = fr, fh_e = fh, lane_e = lane;            // (opaque copies: keeps the epilogue's addresses out of the
+            asm volatile("" : "+v"(fr_e), "+v"(fh_e), "+v"(lane_e));  //  persistent loop's invariant set, where they would spill)
+            const int ch = lane_e & 7;
+            const int col = cur.tile_n * BN + wn * WTN + ch * 8;
+            int ct_ph = 0, ct_co = 0;
+            if (CTF) gdt_ctf_column(col, d.phase_cout, ct_ph, ct_co);
+            float st1[8], st2[8];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+            float4 bvs[TN][4];                                   // bias of this lane's channels, fetched once per tile
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { st1[r][e] = 0.f; st2[r][e] = 0.f; }
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < NHALF; ++p) {
-                if (p == 1) __syncthreads();                   // the stores of the first half have read the region
+                for (int g = 0; g < 4; ++g)
+                    bvs[j][g] = d.bias ? *(const float4*)(d.bias + cur.tile_n * BN + wn * WTN + j * 32 + 8 * g + 4 * fh_e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = wn * WTN + j * 32 + 8 * g + 4 * fh_e;
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (d.bias) bv = *(const float4*)(d.bias + cur.tile_n * BN + col);
-#pragma unroll
-                        for (int ii = 0; ii < HT; ++ii) {
-                            const int rr = wm * HROWS + ii * 32 + fr_e;
-                            const f32x16& a = acc[p * HT + ii][j];
-                            float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
-                            if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                            f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
-                            *(f16x4*)(Ct + rr * CP + col) = h;
-                        }
+                        const float4 bv = bvs[j][g];
+                        const f32x16& a = acc[i][j];
+                        float v0 = a[4 * g] + bv.x, v1 = a[4 * g + 1] + bv.y, v2 = a[4 * g + 2] + bv.z, v3 = a[4 * g + 3] + bv.w;
+                        if (relu_now) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
+                        *(f16x4*)(patch + fr_e * PCP + j * 32 + 8 * g + 4 * fh_e) = h;
                     }
-                __syncthreads();
-                constexpr int QB = NCHH >= 4 ? 4 : NCHH;       // residual loads in flight per thread
+                unsigned offs[4];
+                f16x8 rv[4];
+                unsigned okmask = 0;
 #pragma unroll
-                for (int qb = 0; qb < NCHH; qb += QB) {
-                    unsigned offs[QB];
-                    f16x8 rv[QB];
-                    unsigned okmask = 0;
-#pragma unroll
-                    for (int qq = 0; qq < QB; ++qq) {
-                        const int id = (qb + qq) * NT + tid_e;
-                        const int rr = id / CPR;
-                        const int row = (rr / HROWS) * WTM + p * HROWS + (rr % HROWS);
-                        const int col = cur.tile_n * BN + (id % CPR) * 8;
-                        const int m = cur.tile_m * BM + row;
-                        const bool ok = (m < d.M) & (col < d.Cout);
-                        unsigned pix = (unsigned)m;                              // dense output grid: the GEMM row IS the pixel
-                        if (d.phase_cout) {                                      // fused transposed conv: column block -> sub-pixel
-                            const int mm = m < d.M ? m : 0;
-                            const int n = mm / hw_g, rem = mm - n * hw_g;
-                            const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
-                            int ph, co;
-                            gdt_ctf_column(col, d.phase_cout, ph, co);
-                            pix = (unsigned)((n * d.OH + 2 * oy + (ph >> 1)) * d.OW + 2 * ox + (ph & 1));
-                            offs[qq] = ok ? pix * (unsigned)d.phase_cout + co : 0u;
-                        } else if (!dense) {                                            // (ConvTranspose2d phases: every other row / column)
-                            const int mm = m < d.M ? m : 0;
-                            const int n = mm / hw_g, rem = mm - n * hw_g;
-                            const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
-                            pix = (unsigned)((n * d.OH + oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox);
-                        }
-                        if (!d.phase_cout) offs[qq] = ok ? pix * (unsigned)d.Cout + col : 0u;
-                        okmask |= (ok ? 1u : 0u) << qq;
-                        if (has_res) rv[qq] = *(const f16x8*)(d.res + offs[qq]);   // offset 0 is a valid address for masked chunks
+                for (int q = 0; q < 4; ++q) {
+                    const int m = cur.tile_m * BM + wm * WTM + i * 32 + (lane_e >> 3) + 8 * q;
+                    const bool ok = (m < d.M) & (col < d.Cout);
+                    unsigned pix = (unsigned)m;                              // dense output grid: the GEMM row IS the pixel
+                    if (CTF || !dense) {                                     // (transposed convs: every other row / column)
+                        const int mm = m < d.M ? m : 0;
+                        const int n = mm / hw_g, rem = mm - n * hw_g;
+                        const int oy = rem / d.OWg, ox = rem - oy * d.OWg;
+                        pix = CTF ? (unsigned)((n * d.OH + 2 * oy + (ct_ph >> 1)) * d.OW + 2 * ox + (ct_ph & 1))
+                                  : (unsigned)((n * d.OH + oy * d.osy + d.ooy) * d.OW + ox * d.osx + d.oox);
                     }
-#pragma unroll
-                    for (int qq = 0; qq < QB; ++qq) {
-                        const int id = (qb + qq) * NT + tid_e;
-                        f16x8 v = *(const f16x8*)(Ct + (id / CPR) * CP + (id % CPR) * 8);
-                        if (d.stats) {
-                            const int rec = (qb + qq) >= NCHH / 2 ? 1 : 0;       // (compile-time after unrolling; region rows are wave-major)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; st1[rec][e] += f; st2[rec][e] += f * f; }
-                        }
-                        if (has_res) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                float t = (float)v[e] + (float)rv[qq][e];
-                                if (d.relu) t = fmaxf(t, 0.f);
-                                v[e] = (f16)t;
-                            }
-                        }
-                        if (((okmask >> qq) & 1u) && !(d.dbg & 8)) *(f16x8*)(d.out + offs[qq]) = v;
-                    }
+                    offs[q] = ok ? (CTF ? pix * (unsigned)d.phase_cout + ct_co : pix * (unsigned)d.Cout + col) : 0u;
+                    okmask |= (ok ? 1u : 0u) << q;
+                    if (has_res) rv[q] = *(const f16x8*)(d.res + offs[q]);     // offset 0 is a valid address for masked pieces
                 }
-            }
-            if (d.stats) {      // 128-row records: lanes sharing a channel group, then the 8 waves, in a fixed order
-                static_assert(NCHH >= 2, "two records per region");
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    f16x8 v = *(const f16x8*)(patch + ((lane_e >> 3) + 8 * q) * PCP + ch * 8);
+                    if (d.stats && ((okmask >> q) & 1u)) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                        for (int msk = CPR; msk < 64; msk <<= 1) { st1[r][e] += __shfl_xor(st1[r][e], msk); st2[r][e] += __shfl_xor(st2[r][e], msk); }
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; st1[e] += f; st2[e] += f * f; }
                     }
-                __syncthreads();                                   // every read of the transpose region is done: reuse it
-                float* F = (float*)Ct;                             // [wave][record][BN][2]
-                if ((tid_e & 63) < CPR) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                    if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            float* f = F + (((tid_e >> 6) * 2 + r) * BN + (tid_e & 63) * 8 + e) * 2;
-                            f[0] = st1[r][e]; f[1] = st2[r][e];
+                            float t = (float)v[e] + (float)rv[q][e];
+                            if (d.relu) t = fmaxf(t, 0.f);
+                            v[e] = (f16)t;
                         }
-                }
-                __syncthreads();
-                if (tid_e < BN * 2) {
-                    const int rec = tid_e / BN, col = tid_e % BN;
-                    const int grec = cur.tile_m * 2 + rec;
-                    if (!d.phase_cout) {
-                        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + col) * 2]; t2 += F[((w * 2 + rec) * BN + col) * 2 + 1]; }
-                        const int gcol = cur.tile_n * BN + col;
-                        if (gcol < d.Cout && grec * 128 < d.M) {
-                            float* dst = d.stats + ((long)(d.stats_tile_base + grec) * 2) * d.Cout + gcol;
-                            dst[0] = t1; dst[d.Cout] = t2;
-                        }
-                    } else if (col < d.phase_cout && grec * 128 < d.M) {
-                        // fused transposed conv: the sub-pixel phases held by this N tile are merged per channel; one record
-                        // set per N tile (the finalize kernel sums them like the phase launches' sets)
-                        float t1 = 0.f, t2 = 0.f;
-                        for (int blk = 0; blk < BN / 32; ++blk) {           // column blocks of this N tile that hold channel `col`
-                            int ph, co;
-                            gdt_ctf_column(cur.tile_n * BN + blk * 32 + (col & 31), d.phase_cout, ph, co);
-                            if (co != col) continue;
-                            const int c2 = blk * 32 + (col & 31);
-#pragma unroll
-                            for (int w = 0; w < 8; ++w) { t1 += F[((w * 2 + rec) * BN + c2) * 2]; t2 += F[((w * 2 + rec) * BN + c2) * 2 + 1]; }
-                        }
-                        float* dst = d.stats + ((long)(cur.tile_n * (d.M / 128) + grec) * 2) * d.phase_cout + col;
-                        dst[0] = t1; dst[d.phase_cout] = t2;
                     }
+                    if (((okmask >> q) & 1u) && !(d.dbg & 8)) *(f16x8*)(d.out + offs[q]) = v;
+                }
+            }
+            if (d.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
+                    if (CTF) { st1[e] += __shfl_xor(st1[e], 4); st2[e] += __shfl_xor(st2[e], 4); }     // the wave's two sub-pixel phases of a channel
+                }
+                constexpr int WPR = WGM / 2;                         // wave rows per 128-row record
+                const int rec = cur.tile_m * 2 + wm / WPR;
+                if (!CTF && lane_e < 8 && col < d.Cout && rec * 128 < d.M) {
+                    float* dst = d.stats + ((long)(d.stats_tile_base + (wm % WPR) * (d.M / 128) + rec) * 2) * d.Cout + col;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { dst[e] = st1[e]; dst[d.Cout + e] = st2[e]; }
+                }
+                if (CTF && lane_e < 4 && rec * 128 < d.M) {          // one record set per phase pair (gdt_ctf_column)
+                    const int pair = ((cur.tile_n * WGN + wn) / (d.phase_cout >> 5)) & 1;
+                    float* dst = d.stats + ((long)(pair * (d.M / 128) + rec) * 2) * d.phase_cout + ct_co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { dst[e] = st1[e]; dst[d.phase_cout + e] = st2[e]; }
                 }
             }
         }
@@ -424,7 +369,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm_rb_kernel(const Con
         cur = nxt; vb += gridDim.x;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) load_b(kk, cur.tile_n, 0);
-        __syncthreads();          // (the statistics scratch and the transpose region are free again)
 #pragma unroll
         for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0);
     }
@@ -454,13 +398,20 @@ int launch_irb(const ConvLaunch& d, hipStream_t stream) {
 // Eligible: fp16 NHWC in and out, Cin a multiple of 64, fragment-ordered weights, at least two K-steps (the A tile is staged
 // two steps ahead), tensors addressable with 32-bit element offsets, enough tiles to fill the chip; with a folded
 // InstanceNorm additionally Cin <= 256 and whole tiles inside one image.
+// record sets written for a launch with fused statistics: waves whose WTM rows are a fraction of a 128-row record write to
+// separate sets (BN 256: 1, 128: 2, 64: 4); the fused transposed form writes one per phase pair
+int gdt_conv_igemm_rb_stats_sets(const ConvLaunch& d) {
+    if (d.phase_cout) return 2;
+    return d.CoutPad % 256 == 0 ? 1 : (d.CoutPad % 128 == 0 ? 2 : 4);
+}
+
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_IRB"); return e ? atoi(e) : 1; }();   // 0 off, 2 force
     if (mode == 0 || !d.w_frag || d.out_f32 || !d.out || d.Cin % 64 != 0 || d.Kpad != d.ntaps * d.Cin || d.Kpad < 128) return false;
     if (d.CoutPad % 64 != 0 || d.Cout % 8 != 0 || d.in_res || d.in_out) return false;
     if (d.phase_cout && (d.CoutPad % 256 != 0 || 256 % d.phase_cout != 0 || d.phase_cout < 64 || d.Cout != 4 * d.phase_cout || d.res || d.M % 128 != 0)) return false;
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.OH * d.OW * (d.phase_cout ? d.phase_cout : d.Cout) >= (1L << 32)) return false;
-    if (d.stats && ((d.OHg * d.OWg) % 128 != 0 || d.CoutPad % 256 != 0)) return false;    // (narrower tiles with statistics: conv_igemm.hip measured faster)
+    if (d.stats && ((d.OHg * d.OWg) % 128 != 0 || d.CoutPad % 128 != 0 || d.M % 128 != 0)) return false;    // (64-wide tiles with statistics: conv_igemm.hip measured faster)
     if (d.in_norm && (d.Cin > 256 || (d.OHg * d.OWg) % BM != 0)) return false;
     if (mode == 2) return true;
     // Sustained (power-throttled) A/B runs on 1x MI355X -- bench.py back to back with GDT_CONV_IRB=0/1, tools_layer_bench.py per

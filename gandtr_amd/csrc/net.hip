@@ -243,8 +243,8 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                     want = uses == 1 && (gdt_conv_igemm_rb_eligible(dn) || gdt_conv_halo_ct_eligible(dn));
                 }
         }
-        // record sets the finalize kernel sums: the LDS-resident kernel writes one per phase pair, the generic one per N tile
-        if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = gdt_conv_halo_ct_eligible(d) ? 2 : d.CoutPad / 256; }
+        // record sets the finalize kernel sums: one per phase pair
+        if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
     }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
@@ -300,6 +300,20 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
         static const bool plan_dbg = getenv("GDT_PLAN_DEBUG") != nullptr;
         if (plan_dbg) fprintf(stderr, "[plan] inorm %d -> conv %d: Cin %d s%d k%d rowsplit %d fold %d\n", j, k, d.Cin, ok.cd.stride, ok.cd.kh, (int)ok.rowsplit, (int)fold);
+    }
+
+    // ---- statistics record sets of the convs that run on conv_igemm_rb.hip (same order of choice as gdt_launch_conv)
+    for (int i = 0; i < nops; ++i) {
+        const Op& o = ops[i];
+        if (o.kind != OP_CONV || plan.steps[i].ctf || o.cd.transposed || o.rowsplit || o.cd.out_f32_nchw || net->precision) continue;
+        if (!conv_fuses_stats(o, T[o.in])) continue;
+        ConvLaunch d{};
+        conv_geometry(net, o, o.phases[0], N, T[o.in], d);
+        d.w_frag = o.phases[0].has_frag ? (const f16*)net : nullptr; d.out = (f16*)net; d.stats = (float*)net;       // markers only
+        d.in_norm = plan.steps[i].norm_from >= 0 ? (const float*)net : nullptr;
+        if (plan.steps[i].norm_from >= 0 && plan.steps[plan.steps[i].norm_from].wb) continue;                      // (patch kernels)
+        if (!gdt_conv_stem_eligible(d) && !gdt_conv_halo_rb_eligible(d) && !gdt_conv_halo_eligible(d) && gdt_conv_igemm_rb_eligible(d))
+            plan.steps[i].stats_sets = gdt_conv_igemm_rb_stats_sets(d);
     }
 
     // ---- pass 2b: MaxPool2d(2, 2) fused into the epilogue of its producer (VGG16 stages): conv -> pool with no other consumer
