@@ -414,13 +414,12 @@ bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d) {
     if (d.stats && ((d.OHg * d.OWg) % 128 != 0 || d.CoutPad % 128 != 0 || d.M % 128 != 0)) return false;    // (64-wide tiles with statistics: conv_igemm.hip measured faster)
     if (d.in_norm && (d.Cin > 256 || (d.OHg * d.OWg) % BM != 0)) return false;
     if (mode == 2) return true;
-    // Sustained (power-throttled) A/B runs on 1x MI355X -- bench.py back to back with GDT_CONV_IRB=0/1, tools_layer_bench.py per
-    // layer -- show this kernel ahead only where it also removes an InstanceNorm pass (Cin > 64 inputs the first kernel
-    // cannot normalise while staging); on the plain 1x1 convs of ResNet-101 it is within +-3 % of conv_igemm.hip (whole net
-    // 1526 vs 1545 descriptors/s) although the event-timed per-op profile had it 22 % faster (9.4 vs 12.1 ms over 58 launches).
-    if (mode == 1 && !d.in_norm && !d.phase_cout) return false;
+    // History (sustained bench.py A/B runs on 1x MI355X): with the whole-tile LDS transpose and its barriers this kernel tied
+    // with conv_igemm.hip on the plain 1x1 convs of ResNet-101 (1526 vs 1545 descriptors/s) and was used only where it also
+    // folds an InstanceNorm; with the wave-private epilogue it is ahead there too (1777 vs 1671).
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
-    return (long)((d.M + BM - 1) / BM) * (d.CoutPad / bn) >= 512;
+    static const int min_tiles = [] { const char* e = getenv("GDT_IRB_MIN_TILES"); return e ? atoi(e) : 256; }();
+    return (long)((d.M + BM - 1) / BM) * (d.CoutPad / bn) >= min_tiles;
 }
 
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
