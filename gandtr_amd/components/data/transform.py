@@ -54,6 +54,11 @@ class ImageClahe:
         self.clip_limit, self.grid_size, self.colorspace = clip_limit, grid_size, colorspace
 
     def apply(self, img):
+        if isinstance(img, torch.Tensor) and img.is_cuda:       # H x W x 3 on a HIP device: gandtr_amd/csrc/clahe.hip
+            if self.colorspace != "lab":
+                raise NotImplementedError("only the 'lab' colorspace is supported")
+            from ... import clahe
+            return clahe.clahe_lab(img.permute(2, 0, 1)[None], self.clip_limit, self.grid_size)[0].permute(1, 2, 0)
         try:
             import cv2
         except ImportError as e:          # pragma: no cover - depends on the image

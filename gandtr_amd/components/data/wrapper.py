@@ -237,8 +237,8 @@ class CirtorchWhiten(Wrapper):
 
 
 class ClahePost(Wrapper):
-    """cv2 CLAHE on the network output (device -> CPU -> cv2 -> device per image, as in the reference).  This is a
-    "next" row of SURVEY.md section 8f (GPU CLAHE); it needs opencv, which is optional."""
+    """CLAHE on the network output (wrapper.py:325-348).  Tensors on a HIP device go through gandtr_amd.clahe (whole batch, three
+    launches, no host round trip); host tensors take the reference's cv2 route, which needs opencv (optional)."""
 
     def __init__(self, meanstd, clip_limit=4, grid_size=8, colorspace="lab", *, device):
         super().__init__(device)
@@ -251,6 +251,14 @@ class ClahePost(Wrapper):
             return tensor
         if isinstance(tensor, list):
             return [self.postprocess(x, outputmodel, meta) for x in tensor]
+        if _on_hip(tensor) and tensor.dim() in (3, 4):
+            if self.clahe.colorspace.lower() != "lab":
+                raise NotImplementedError("Colorspace %s is not supported on the HIP path" % self.clahe.colorspace)
+            from ... import clahe
+            pair = (self.meanstd[0], self.meanstd[1])
+            batch = tensor if tensor.dim() == 4 else tensor[None]
+            out = clahe.clahe_lab(batch, self.clahe.clip_limit, self.clahe.grid_size, pair, pair)
+            return out if tensor.dim() == 4 else out[0]
         if tensor.dim() == 4:
             return torch.stack([self.postprocess(x, outputmodel, meta) for x in tensor])
         if tensor.dim() == 3:

@@ -155,6 +155,24 @@ int gdt_retrieval_scores_ranks(const float* vecs, const float* qvecs, float* sco
                                int index_base, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * CLAHE post-processing ("next" row of SURVEY.md section 8f, rank 1: the step between generator and embedder)
+ * Replaces the per-image device -> CPU -> cv2 -> device round trip of
+ *   ClahePost.postprocess   mdir/components/data/wrapper.py:325-348
+ *   ImageClahe.apply        mdir/components/data/transform/functional.py:81-85,147-158 (colorspace "lab": :28-36, :55-63)
+ * gdt_clahe_u8: cv2.createCLAHE(clip_limit, (tiles_x, tiles_y)).apply on n uint8 planes [n][h][w] (device buffers).
+ * gdt_clahe_lab_f32: x, y fp32 [n][3][h][w] RGB planes (device); rgb = x * in_scale + in_shift (host float[3], NULL = identity),
+ *   RGB -> Lab, L quantised to 8 bits, CLAHE, Lab -> RGB, y = (rgb - out_mean) / out_std (host float[3], NULL = identity).
+ *   ClahePost(meanstd) is in_scale = out_std = std, in_shift = out_mean = mean.
+ * workspace: device scratch of gdt_clahe_workspace_bytes (tile histograms, lookup tables, the 8-bit lightness plane).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int gdt_clahe_workspace_bytes(int n, int h, int w, int tiles_x, int tiles_y, size_t* bytes);
+int gdt_clahe_u8(const unsigned char* src, unsigned char* dst, int n, int h, int w, double clip_limit, int tiles_x, int tiles_y,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int gdt_clahe_lab_f32(const float* x, float* y, int n, int h, int w, const float* in_scale, const float* in_shift, const float* out_mean,
+                      const float* out_std, double clip_limit, int tiles_x, int tiles_y, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): sustained rate of the matrix pipe alone on this device -- a kernel of nothing
  * but v_mfma_f32_32x32x16_f16 on random fp16 operands (8 independent accumulators per wave, 8 waves per CU) run for about
  * `millis` milliseconds.  bench.py reports it next to the 2.5 PFLOP/s datasheet peak: these boxes throttle to 1.5-1.7 PFLOP/s
