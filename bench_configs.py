@@ -6,6 +6,7 @@
   c3  gem_resnet101_hedngan multi-scale descriptors + lw whitening, 3x1024x1024       -> descriptors/s
       (scales hub default {1, 1/sqrt2, 1/2} and 'sms' {1, 1/sqrt2, sqrt2}; one rank's share of the 8-GPU job)
   c4  augment-then-embed: cyclegan on 128x3x256x256 -> meanstd_post -> GeM-ResNet101  -> images/s
+      (+ the same chain with the reference's clahepost step, and the CLAHE / retrieval 'next' rows alone)
 Everything runs through the hub / wrapper / network-container API of the host mirror (the drop-in surface).
 """
 import json
@@ -116,6 +117,23 @@ def main():
         x = synth.synth_input(5, (128, 3, 256, 256), 1.0).to(dev)
         r, ms = rate(lambda: chain(x), 128)
         out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1)}
+        # the same chain with the reference's CLAHE step between generator and embedder (finetune.yml:13: wrappers
+        # meanstd_post, clahepost -- post-processing runs in reverse order: CLAHE first, then the ImageNet mean / std)
+        gen_c = json.loads(json.dumps(gen_p))
+        gen_c["runtime"]["wrappers"] += ",clahepost:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:1.0"
+        chain_c = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_c, "embed": emb_p},
+                                       dev).eval()
+        chain_c.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance"))
+        chain_c.networks["embed"].model.load_state_dict(synth.resnet101_state(0))
+        r, ms = rate(lambda: chain_c(x), 128)
+        out["c4_with_clahepost_128x256"] = {"images_per_s": r, "ms_per_batch": ms}
+        # "next" row: CLAHE post-processing alone, 38 algorithmic bytes per pixel
+        from gandtr_amd import clahe
+        y = chain.networks["augment"].model(x)
+        pair = ([0.5] * 3, [0.5] * 3)
+        r, ms = rate(lambda: clahe.clahe_lab(y, 1.0, 8, pair, pair), 128, steps=50, warmup=5)
+        out["next_clahe_post_128x256"] = {"images_per_s": r, "us": round(128 / r * 1e6, 1), "hbm_GBps_algorithmic": round(38 * 65536 * r / 1e9, 1)}
+        del chain_c, y
         # "next" row: retrieval scoring, revisitop-style: 200k database x 70 queries, D = 2048
         from gandtr_amd import retrieval
         import numpy as np
