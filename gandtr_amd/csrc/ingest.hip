@@ -1,0 +1,294 @@
+// Image ingest after decoding: Pillow's `img.thumbnail((s, s), LANCZOS)` and the
+// `pil2np | totensor | normalize` transforms on the device, bit for bit.
+//   imresize                       mdir/external/cirtorch/datasets/datahelpers.py:75-82
+//   ImagesFromList.__getitem__     mdir/external/cirtorch/datasets/genericdataset.py:66-102
+//   Pil2Numpy / ToTensor / Normalize   mdir/components/data/transform/core_transforms.py:35-100
+// The arithmetic is Pillow's (libImaging Reduce.c / Resample.c; oracle/ingest_oracle.py is the restatement, pinned against the
+// installed Pillow):  optional integer box reduction `((sum + n/2) * uint32(2^32 / (256 n))) >> 24`, then a horizontal and a
+// vertical 8-bit resampling pass, each `clip8((2^21 + sum pixel * k) >> 22)` with 22-bit fixed-point Lanczos-3 weights.  The
+// weights are computed on the host in double precision exactly as Pillow does (same libm) and kept device-resident in a small
+// plan cache (datasets have few distinct geometries); the pixel work is integer, so results are identical to Pillow's.
+// HBM-bound byte work: source read once (reduce or horizontal pass), one 8-bit intermediate, fp32 CHW written once.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "../../include/gandtr_hip.h"
+#include "gdt_common.h"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+// ---- host: Pillow's precompute_coeffs + normalize_coeffs_8bpc -------------------------------------------------------------
+double sinc_filter(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+double lanczos_filter(double x) {
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+
+struct Coeffs {
+    int out_size = 0, ksize = 0;
+    std::vector<int> bounds;      // [out][2]: first source index, tap count
+    std::vector<int> kk;          // [out][ksize] fixed point
+};
+
+void precompute_coeffs(int in_size, float in0, float in1, int out_size, Coeffs& c) {
+    double scale, filterscale;
+    filterscale = scale = (double)(in1 - in0) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    c.out_size = out_size;
+    c.ksize = ksize;
+    c.bounds.assign((size_t)out_size * 2, 0);
+    c.kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = in0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            c.kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PRECISION_BITS)) : (int)(0.5 + k[x] * (1 << PRECISION_BITS));
+        }
+        c.bounds[2 * xx] = xmin;
+        c.bounds[2 * xx + 1] = xmax;
+    }
+}
+
+// ---- device-resident plan cache ---------------------------------------------------------------------------------------------
+struct DevCoeffs {
+    int ksize = 0, first = 0, last = 0;      // first / last: source rows (or columns) touched by the whole axis
+    int* bounds = nullptr;
+    int* kk = nullptr;
+};
+typedef std::tuple<int, int, unsigned, unsigned, int> AxisKey;      // device, in_size, bits(in0), bits(in1), out_size
+std::mutex g_mu;
+std::map<AxisKey, DevCoeffs> g_cache;
+
+unsigned bits_of(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+
+int axis_coeffs(int in_size, float in0, float in1, int out_size, hipStream_t stream, DevCoeffs& out) {
+    int dev = 0;
+    GDT_CHECK_HIP(hipGetDevice(&dev));
+    const AxisKey key(dev, in_size, bits_of(in0), bits_of(in1), out_size);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) { out = it->second; return GDT_OK; }
+    if (g_cache.size() >= 256) {                                     // bounded: drop everything (tables are tiny, rebuilt on demand)
+        GDT_CHECK_HIP(hipDeviceSynchronize());
+        for (auto& e : g_cache) { (void)hipFree(e.second.bounds); (void)hipFree(e.second.kk); }
+        g_cache.clear();
+    }
+    Coeffs c;
+    precompute_coeffs(in_size, in0, in1, out_size, c);
+    DevCoeffs d;
+    d.ksize = c.ksize;
+    d.first = c.bounds[0];
+    d.last = c.bounds[2 * (out_size - 1)] + c.bounds[2 * (out_size - 1) + 1];
+    GDT_CHECK_HIP(hipMalloc(&d.bounds, c.bounds.size() * sizeof(int)));
+    GDT_CHECK_HIP(hipMalloc(&d.kk, c.kk.size() * sizeof(int)));
+    GDT_CHECK_HIP(hipMemcpy(d.bounds, c.bounds.data(), c.bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+    GDT_CHECK_HIP(hipMemcpy(d.kk, c.kk.data(), c.kk.size() * sizeof(int), hipMemcpyHostToDevice));
+    g_cache[key] = d;
+    out = d;
+    return GDT_OK;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned clip8(int ss) { return (unsigned)min(max(ss >> PRECISION_BITS, 0), 255); }
+
+// Image.reduce((fx, fy)) over the full image; one lane per output pixel (C channels).  Partial boxes at the right / bottom edge
+// average over their own pixel count (ImagingReduceCorners).
+template <int C>
+__global__ __launch_bounds__(256) void reduce_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int h, int w, int fx,
+                                                     int fy, int oh, int ow) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const int x0 = ox * fx, y0 = oy * fy, nx = min(fx, w - x0), ny = min(fy, h - y0);
+    unsigned ss[C] = {};
+    for (int y = 0; y < ny; ++y) {
+        const unsigned char* p = src + ((size_t)(y0 + y) * w + x0) * C;
+        for (int x = 0; x < nx; ++x)
+#pragma unroll
+            for (int c = 0; c < C; ++c) ss[c] += p[x * C + c];
+    }
+    const unsigned n = (unsigned)(nx * ny);
+    const unsigned mult = (unsigned)(4294967296.0f / (float)(256u * n));       // division_UINT32(n, 8)
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        dst[((size_t)oy * ow + ox) * C + c] = (unsigned char)(((unsigned long long)(ss[c] + n / 2) * mult) >> 24);
+}
+
+// horizontal pass: rows [first, last) of src (w pixels) -> tmp [(last - first)][ow][C]
+template <int C>
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ tmp, int w, int first,
+                                                         int rows, int ow, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+    const int xx = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xx >= ow || y >= rows) return;
+    const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int* k = kk + (size_t)xx * ksize;
+    const unsigned char* p = src + ((size_t)(first + y) * w + x0) * C;
+    int ss[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ss[c] = 1 << (PRECISION_BITS - 1);
+    for (int t = 0; t < n; ++t) {
+        const int kv = k[t];
+#pragma unroll
+        for (int c = 0; c < C; ++c) ss[c] += (int)p[t * C + c] * kv;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) tmp[((size_t)y * ow + xx) * C + c] = (unsigned char)clip8(ss[c]);
+}
+
+// vertical pass (bounds relative to the image it reads: `shift` = first row of the horizontal pass, 0 without one), fused with
+// the output conversions: 8-bit HWC and / or fp32 CHW `(v / 255 - mean) / std` (Pil2Numpy, ToTensor, Normalize; IEEE division)
+template <int C>
+__global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __restrict__ tmp, int ow, int oh, int shift,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int vertical,
+                                                         unsigned char* __restrict__ dst_hwc, float* __restrict__ dst_chw, float m0, float m1,
+                                                         float m2, float m3, float s0, float s1, float s2, float s3) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || yy >= oh) return;
+    unsigned v[C];
+    if (vertical) {
+        const int y0 = bounds[2 * yy] - shift, n = bounds[2 * yy + 1];
+        const int* k = kk + (size_t)yy * ksize;
+        int ss[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) ss[c] = 1 << (PRECISION_BITS - 1);
+        for (int t = 0; t < n; ++t) {
+            const int kv = k[t];
+            const unsigned char* p = tmp + ((size_t)(y0 + t) * ow + x) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) ss[c] += (int)p[c] * kv;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = clip8(ss[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = tmp[((size_t)yy * ow + x) * C + c];
+    }
+    const float mean[4] = {m0, m1, m2, m3}, stdv[4] = {s0, s1, s2, s3};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (dst_hwc) dst_hwc[((size_t)yy * ow + x) * C + c] = (unsigned char)v[c];
+        if (dst_chw) dst_chw[((size_t)c * oh + yy) * ow + x] = ((float)v[c] / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct IngestPlan {
+    int rh, rw;                 // size after the box reduction
+    size_t reduced, tmp, total; // workspace offsets
+};
+
+int plan_ingest(int h, int w, int c, int fx, int fy, int out_w, int out_h, IngestPlan& p) {
+    GDT_REQUIRE(h >= 1 && w >= 1 && out_w >= 1 && out_h >= 1, "ingest: empty image");
+    GDT_REQUIRE(c >= 1 && c <= 4, "ingest: 1..4 interleaved 8-bit channels");
+    GDT_REQUIRE(fx >= 1 && fy >= 1 && fx <= w && fy <= h, "ingest: reduction factors must be within the image");
+    GDT_REQUIRE((long)h * w < (1l << 30) && (long)out_h * out_w < (1l << 30), "ingest: image too large");
+    p.rh = (h + fy - 1) / fy;
+    p.rw = (w + fx - 1) / fx;
+    size_t off = 0;
+    p.reduced = off; off += (fx > 1 || fy > 1) ? align_up((size_t)p.rh * p.rw * c) : 0;
+    p.tmp = off; off += align_up((size_t)p.rh * out_w * c);           // upper bound: every reduced row
+    p.total = off + ALIGN;
+    return GDT_OK;
+}
+
+template <int C>
+int run_ingest(const unsigned char* src, int h, int w, int fx, int fy, const float* box, int out_w, int out_h, unsigned char* dst_hwc,
+               float* dst_chw, const float* mean, const float* stdv, char* ws, const IngestPlan& p, hipStream_t stream) {
+    const unsigned char* cur = src;
+    int ch = h, cw = w;
+    if (fx > 1 || fy > 1) {
+        unsigned char* red = (unsigned char*)(ws + p.reduced);
+        hipLaunchKernelGGL(reduce_kernel<C>, dim3((p.rw + 63) / 64, (p.rh + 3) / 4), dim3(256), 0, stream, src, red, h, w, fx, fy, p.rh, p.rw);
+        cur = red; ch = p.rh; cw = p.rw;
+    }
+    // ImagingResample: which passes are needed (Resample.c)
+    const bool need_h = out_w != cw || box[0] != 0.f || box[2] != (float)out_w;
+    const bool need_v = out_h != ch || box[1] != 0.f || box[3] != (float)out_h;
+    DevCoeffs kh, kv;
+    int rc = axis_coeffs(ch, box[1], box[3], out_h, stream, kv);
+    if (rc != GDT_OK) return rc;
+    int first = 0, rows = ch;
+    if (need_v) { first = kv.first; rows = kv.last - kv.first; }
+    const unsigned char* vin = cur;
+    int shift = 0;
+    if (need_h) {
+        rc = axis_coeffs(cw, box[0], box[2], out_w, stream, kh);
+        if (rc != GDT_OK) return rc;
+        unsigned char* tmp = (unsigned char*)(ws + p.tmp);
+        hipLaunchKernelGGL(resample_h_kernel<C>, dim3((out_w + 63) / 64, (rows + 3) / 4), dim3(256), 0, stream, cur, tmp, cw, first, rows, out_w,
+                           kh.bounds, kh.kk, kh.ksize);
+        vin = tmp;
+        shift = first;
+    }
+    float m[4] = {0, 0, 0, 0}, s[4] = {1, 1, 1, 1};
+    for (int i = 0; i < C; ++i) { if (mean) m[i] = mean[i]; if (stdv) s[i] = stdv[i]; }
+    hipLaunchKernelGGL(resample_v_kernel<C>, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(256), 0, stream, vin, out_w, out_h, shift, kv.bounds,
+                       kv.kk, kv.ksize, need_v ? 1 : 0, dst_hwc, dst_chw, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3]);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gdt_ingest_workspace_bytes(int h, int w, int c, int fx, int fy, int out_w, int out_h, size_t* bytes) {
+    GDT_REQUIRE(bytes != nullptr, "bytes");
+    IngestPlan p;
+    int rc = plan_ingest(h, w, c, fx, fy, out_w, out_h, p);
+    if (rc != GDT_OK) return rc;
+    *bytes = p.total;
+    return GDT_OK;
+}
+
+int gdt_ingest_resize_u8(const unsigned char* src, int h, int w, int c, int fx, int fy, const float* box, int out_w, int out_h,
+                         unsigned char* dst_hwc, float* dst_chw, const float* mean, const float* std, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    IngestPlan p;
+    int rc = plan_ingest(h, w, c, fx, fy, out_w, out_h, p);
+    if (rc != GDT_OK) return rc;
+    GDT_REQUIRE(src != nullptr && (dst_hwc != nullptr || dst_chw != nullptr) && workspace != nullptr, "ingest: null buffer");
+    float full[4] = {0.f, 0.f, (float)p.rw, (float)p.rh};
+    if (box == nullptr) box = full;
+    GDT_REQUIRE(box[0] >= 0.f && box[1] >= 0.f && box[2] <= (float)p.rw && box[3] <= (float)p.rh && box[2] > box[0] && box[3] > box[1],
+                "ingest: box outside the (reduced) image");
+    if (std) for (int i = 0; i < c; ++i) GDT_REQUIRE(std[i] != 0.f, "ingest: zero std");
+    if (workspace_bytes < p.total) { gdt_set_error("ingest: workspace too small"); return GDT_ERR_WORKSPACE; }
+    char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    switch (c) {
+        case 1: return run_ingest<1>(src, h, w, fx, fy, box, out_w, out_h, dst_hwc, dst_chw, mean, std, ws, p, s);
+        case 2: return run_ingest<2>(src, h, w, fx, fy, box, out_w, out_h, dst_hwc, dst_chw, mean, std, ws, p, s);
+        case 3: return run_ingest<3>(src, h, w, fx, fy, box, out_w, out_h, dst_hwc, dst_chw, mean, std, ws, p, s);
+        default: return run_ingest<4>(src, h, w, fx, fy, box, out_w, out_h, dst_hwc, dst_chw, mean, std, ws, p, s);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Image ingest on the device after decoding.
+
+Reference (per image, on the CPU through Pillow / numpy): ``imresize`` = ``img.thumbnail((s, s), LANCZOS)``
+(mdir/external/cirtorch/datasets/datahelpers.py:75-82, called from genericdataset.py:66-102) followed by the hub transform
+``pil2np | apply_clahe:1.0 | totensor | normalize`` (mdir/hub/embedding.yml:14, core_transforms.py:35-100).
+Here the decoded uint8 H x W x 3 image is uploaded once; resize (bit-identical to Pillow), [0, 1] scaling, optional CLAHE and
+normalisation run as HIP launches (gandtr_amd/csrc/ingest.hip, clahe.hip).  The size / reducing-gap plan below mirrors Pillow's
+Python layer (PIL/Image.py: thumbnail, resize); JPEG decoding stays on the host.  No CPU fallback."""
+import ctypes
+import math
+
+import torch
+
+from . import _hip
+
+
+def thumbnail_size(width, height, imsize):
+    """size Image.thumbnail((imsize, imsize)) resizes to, or None when the image already fits (PIL/Image.py preserve_aspect_ratio)"""
+    x = y = math.floor(imsize)
+    if x >= width and y >= height:
+        return None
+
+    def round_aspect(number, key):
+        return max(min(math.floor(number), math.ceil(number), key=key), 1)
+
+    aspect = width / height
+    if x / y >= aspect:
+        x = round_aspect(y * aspect, key=lambda n: abs(aspect - n / y))
+    else:
+        y = round_aspect(x / aspect, key=lambda n: 0 if n == 0 else abs(aspect - x / n))
+    return x, y
+
+
+def reduce_plan(width, height, out_w, out_h, reducing_gap=2.0):
+    """Image.resize(..., reducing_gap): integer box-reduction factors and the source box of the resampling step (in pixels of the
+    reduced image).  thumbnail passes the full image as the box, for which Pillow's safe box is the full image as well."""
+    fx = int(width / out_w / reducing_gap) or 1
+    fy = int(height / out_h / reducing_gap) or 1
+    if fx > 1 or fy > 1:
+        return fx, fy, (0.0, 0.0, width / fx, height / fy)
+    return 1, 1, (0.0, 0.0, float(width), float(height))
+
+
+def _f(vals, n):
+    if vals is None:
+        return None
+    vals = [float(v) for v in vals]
+    if len(vals) != n:
+        raise ValueError("expected %d per-channel values, got %d" % (n, len(vals)))
+    return (ctypes.c_float * n)(*vals)
+
+
+def resize(img, out_w, out_h, factors=(1, 1), box=None, want_u8=True, mean_std=None, want_chw=False):
+    """Pillow's reduce(factors) + resize((out_w, out_h), LANCZOS, box) on a uint8 H x W x C device tensor.
+    Returns (uint8 out_h x out_w x C or None, fp32 C x out_h x out_w or None)."""
+    lib = _hip.load()
+    if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3:
+        raise ValueError("ingest needs a uint8 H x W x C tensor on a HIP device")
+    img = img.contiguous()
+    h, w, c = img.shape
+    fx, fy = factors
+    dst = torch.empty((out_h, out_w, c), dtype=torch.uint8, device=img.device) if want_u8 else None
+    chw = torch.empty((c, out_h, out_w), dtype=torch.float32, device=img.device) if want_chw else None
+    mean, std = mean_std if mean_std is not None else (None, None)
+    need = ctypes.c_size_t()
+    with torch.cuda.device(img.device):
+        _hip.check(lib.gdt_ingest_workspace_bytes(h, w, c, fx, fy, out_w, out_h, ctypes.byref(need)))
+        ws = torch.empty(need.value, dtype=torch.uint8, device=img.device)
+        _hip.check(lib.gdt_ingest_resize_u8(img.data_ptr(), h, w, c, fx, fy, _f(box, 4), out_w, out_h,
+                                            dst.data_ptr() if want_u8 else None, chw.data_ptr() if want_chw else None,
+                                            _f(mean, c), _f(std, c), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(img.device).cuda_stream))
+    return dst, chw
+
+
+def _plan(img, imsize):
+    h, w, _ = img.shape
+    size = thumbnail_size(w, h, imsize) if imsize is not None else None
+    if size is None:
+        size = (w, h)
+    fx, fy, box = reduce_plan(w, h, size[0], size[1]) if size != (w, h) else (1, 1, None)
+    return size, (fx, fy), box
+
+
+def imresize(img, imsize):
+    """datahelpers.imresize: ``img.thumbnail((imsize, imsize), LANCZOS)`` on a decoded uint8 H x W x C device tensor."""
+    size, factors, box = _plan(img, imsize)
+    if size == (img.shape[1], img.shape[0]):
+        return img
+    return resize(img, size[0], size[1], factors, box)[0]
+
+
+def ingest(img, imsize, mean, std, clahe_clip=None, clahe_grid=8):
+    """decoded uint8 H x W x 3 (device) -> fp32 3 x h x w, what ``imresize`` followed by
+    ``pil2np | [apply_clahe:clip] | totensor | normalize`` produce (hub transform: mdir/hub/embedding.yml:14)."""
+    size, factors, box = _plan(img, imsize)
+    if clahe_clip is None:
+        return resize(img, size[0], size[1], factors, box, want_u8=False, mean_std=(mean, std), want_chw=True)[1]
+    from . import clahe
+    unit = resize(img, size[0], size[1], factors, box, want_u8=False, want_chw=True)[1]          # [0, 1] RGB planes
+    return clahe.clahe_lab(unit[None], clahe_clip, clahe_grid, None, (mean, std))[0]

@@ -173,6 +173,21 @@ int gdt_clahe_lab_f32(const float* x, float* y, int n, int h, int w, const float
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Image ingest after decoding ("next" row of SURVEY.md section 8f, rank 3)
+ * Replaces  img.thumbnail((s, s), LANCZOS)  (mdir/external/cirtorch/datasets/datahelpers.py:75-82, genericdataset.py:66-102)
+ * and  pil2np | totensor | normalize  (mdir/components/data/transform/core_transforms.py:35-100) for a decoded image that
+ * already sits in device memory: src [h][w][c] uint8 interleaved (c = 1..4).  Steps, identical to Pillow's integer arithmetic:
+ * Image.reduce((fx, fy)) when fx or fy > 1, then Image.resize((out_w, out_h), LANCZOS, box) with `box` (4 host floats, in
+ * pixels of the REDUCED image; NULL = all of it).  The caller supplies the plan Pillow's Python layer computes (thumbnail size,
+ * reducing_gap factors, box): gandtr_amd/ingest.py mirrors it.  Outputs (either may be NULL): dst_hwc [out_h][out_w][c] uint8;
+ * dst_chw [c][out_h][out_w] fp32 = (v / 255 - mean[c]) / std[c]  (host float[c]; NULL = 0 / 1).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int gdt_ingest_workspace_bytes(int h, int w, int c, int fx, int fy, int out_w, int out_h, size_t* bytes);
+int gdt_ingest_resize_u8(const unsigned char* src, int h, int w, int c, int fx, int fy, const float* box, int out_w, int out_h,
+                         unsigned char* dst_hwc, float* dst_chw, const float* mean, const float* std, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): sustained rate of the matrix pipe alone on this device -- a kernel of nothing
  * but v_mfma_f32_32x32x16_f16 on random fp16 operands (8 independent accumulators per wave, 8 waves per CU) run for about
  * `millis` milliseconds.  bench.py reports it next to the 2.5 PFLOP/s datasheet peak: these boxes throttle to 1.5-1.7 PFLOP/s

@@ -1,0 +1,83 @@
+"""Image ingest on the GPU (gandtr_amd/csrc/ingest.hip through the C ABI): bit-exact against Pillow's golden vectors, against the
+oracle (itself pinned to Pillow) and -- Pillow being installed on the GPU box -- against a live Pillow call."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gandtr_amd import ingest
+from oracle import ingest_oracle as I
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ingest.npz")
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def test_golden_vectors_from_pillow(cuda_device):
+    g = np.load(GOLD)
+    n = sum(1 for k in g.files if k.startswith("in_"))
+    for i in range(n):
+        got = ingest.imresize(torch.from_numpy(g["in_%d" % i]).to(cuda_device), int(g["imsize_%d" % i])).cpu().numpy()
+        assert got.shape == g["out_%d" % i].shape and np.array_equal(got, g["out_%d" % i]), i
+
+
+@pytest.mark.parametrize("h,w,s", [(600, 800, 362), (333, 500, 362), (500, 375, 362), (1200, 1600, 1024), (1025, 1024, 1024),
+                                   (2500, 1667, 362), (2001, 2999, 362), (97, 4000, 362), (1500, 200, 128), (100, 37, 50), (64, 64, 64),
+                                   (3000, 4000, 1024), (768, 1024, 1024)])
+def test_imresize_bit_exact(cuda_device, h, w, s):
+    a = np.random.default_rng(h + w).integers(0, 256, (h, w, 3)).astype(np.uint8)
+    ref = I.imresize(a, s)
+    got = ingest.imresize(torch.from_numpy(a).to(cuda_device), s).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    p = Image.fromarray(a)
+    p.thumbnail((s, s), Image.LANCZOS)
+    assert np.array_equal(got, np.asarray(p))
+
+
+@pytest.mark.parametrize("c", [1, 2, 4])
+def test_other_channel_counts(cuda_device, c):
+    a = np.random.default_rng(c).integers(0, 256, (300, 411, c)).astype(np.uint8)
+    ref = I.resample_u8(I.reduce_u8(a, 2, 3), 90, 41, (0.0, 0.0, 411 / 2, 100.0))
+    got, _ = ingest.resize(torch.from_numpy(a).to(cuda_device), 90, 41, (2, 3), (0.0, 0.0, 411 / 2, 100.0))
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_fused_tensor_output_is_exact(cuda_device):
+    """imresize + pil2np | totensor | normalize (core_transforms.py:35-100): fp32 CHW, bit-identical to the numpy / torch CPU ops"""
+    a = np.random.default_rng(5).integers(0, 256, (700, 933, 3)).astype(np.uint8)
+    ref = I.to_tensor_normalize(I.imresize(a, 362), MEAN, STD)
+    got = ingest.ingest(torch.from_numpy(a).to(cuda_device), 362, MEAN, STD).cpu().numpy()
+    assert got.shape == ref.shape and got.dtype == np.float32 and np.array_equal(got, ref)
+    small = np.random.default_rng(6).integers(0, 256, (120, 100, 3)).astype(np.uint8)            # already fits: conversions only
+    got = ingest.ingest(torch.from_numpy(small).to(cuda_device), 362, MEAN, STD).cpu().numpy()
+    assert np.array_equal(got, I.to_tensor_normalize(small, MEAN, STD))
+    assert ingest.imresize(torch.from_numpy(small).to(cuda_device), 362).shape == (120, 100, 3)
+
+
+def test_hub_transform_chain_with_clahe(cuda_device):
+    """hub transform `pil2np | apply_clahe:1.0 | totensor | normalize` (embedding.yml:14) after imresize, on the device"""
+    from oracle import clahe_oracle as C
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    a = np.stack([127 + 100 * np.sin(xx / 90) * np.cos(yy / 70), 127 + 90 * np.cos(xx / 50 + yy / 110), 60 + 0.25 * xx], -1)
+    a = np.clip(a + np.random.default_rng(1).normal(0, 6, a.shape), 0, 255).astype(np.uint8)
+    small = I.imresize(a, 256)
+    ref = ((C.image_clahe(small.astype(np.float32) / np.float32(255), 1.0, 8).transpose(2, 0, 1)
+            - np.asarray(MEAN, np.float32)[:, None, None]) / np.asarray(STD, np.float32)[:, None, None])
+    got = ingest.ingest(torch.from_numpy(a).to(cuda_device), 256, MEAN, STD, clahe_clip=1.0).cpu().numpy()
+    diff = np.abs(got - ref)
+    assert got.shape == ref.shape
+    assert float((diff > 2e-3).mean()) < 2e-3 and float(diff.max()) < 0.2      # CLAHE tolerance of tests/test_hip_clahe.py, in 1/std units
+
+
+def test_argument_errors(cuda_device):
+    with pytest.raises(ValueError):
+        ingest.imresize(torch.zeros(8, 8, 3), 4)                                        # not on the device
+    with pytest.raises(ValueError):
+        ingest.resize(torch.zeros(8, 8, 5, dtype=torch.uint8, device=cuda_device), 4, 4)   # > 4 channels
+    with pytest.raises(ValueError):
+        ingest.resize(torch.zeros(8, 8, 3, dtype=torch.uint8, device=cuda_device), 4, 4, (16, 1))   # factor larger than the image
