@@ -196,11 +196,116 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __
     }
 }
 
+// ---- RGB fast paths ----------------------------------------------------------------------------------------------------------
+// Horizontal pass for C = 3: a workgroup produces 64 output columns x 16 rows.  The source span of those columns (<= HSPAN bytes per
+// row) is staged into LDS with aligned 4-byte loads (the naive kernel issues ~3 * taps byte loads per output pixel and is bound by
+// the address unit), the 64 coefficient rows once per workgroup; taps then come from LDS.  tmp rows have a padded stride.
+constexpr int H_ROWS = 16, H_MAXK = 48, HSPAN = 1536;
+__global__ __launch_bounds__(256) void resample_h3_kernel(const unsigned char* __restrict__ src, size_t src_bytes, unsigned char* __restrict__ tmp,
+                                                          int tstride, int w, int first, int rows, int ow, const int* __restrict__ bounds,
+                                                          const int* __restrict__ kk, int ksize) {
+    __shared__ __attribute__((aligned(16))) unsigned char px[H_ROWS][HSPAN + 8];
+    __shared__ int kl[64 * H_MAXK];
+    __shared__ int delta[H_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xx0 = blockIdx.x * 64, y0 = blockIdx.y * H_ROWS;
+    const int ncol = min(64, ow - xx0), nrow = min(H_ROWS, rows - y0);
+    const int x_lo = bounds[2 * xx0], x_hi = bounds[2 * (xx0 + ncol - 1)] + bounds[2 * (xx0 + ncol - 1) + 1];
+    const int span = (x_hi - x_lo) * 3;                                       // bytes per row (<= HSPAN, checked by the launcher)
+    for (int i = tid; i < ncol * ksize; i += 256) kl[i] = kk[(size_t)xx0 * ksize + i];
+    for (int r = wave; r < nrow; r += 4) {
+        const size_t base = ((size_t)(first + y0 + r) * w + x_lo) * 3;
+        const size_t a0 = base & ~(size_t)3;
+        if (lane == 0) delta[r] = (int)(base - a0);
+        const int nd = (int)((base + span - a0 + 3) >> 2);
+        for (int i = lane; i < nd; i += 64) {
+            const size_t a = a0 + 4 * (size_t)i;
+            unsigned v;
+            if (a + 4 <= src_bytes) v = *(const unsigned*)(src + a);
+            else { v = 0; for (int b = 0; b < 4; ++b) if (a + b < src_bytes) v |= (unsigned)src[a + b] << (8 * b); }
+            *(unsigned*)&px[r][4 * i] = v;
+        }
+    }
+    __syncthreads();
+    if (lane >= ncol) return;
+    const int xx = xx0 + lane;
+    const int off = (bounds[2 * xx] - x_lo) * 3, n = bounds[2 * xx + 1];
+    const int* k = kl + lane * ksize;
+    for (int r = wave; r < nrow; r += 4) {
+        const unsigned char* p = &px[r][delta[r] + off];
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int t = 0; t < n; ++t) {
+            const int kv = k[t];
+            s0 += (int)p[3 * t] * kv; s1 += (int)p[3 * t + 1] * kv; s2 += (int)p[3 * t + 2] * kv;
+        }
+        unsigned char* o = tmp + (size_t)(y0 + r) * tstride + xx * 3;
+        o[0] = (unsigned char)clip8(s0); o[1] = (unsigned char)clip8(s1); o[2] = (unsigned char)clip8(s2);
+    }
+}
+
+// Vertical pass for C = 3 on rows of 4-byte-aligned stride: a lane owns four pixels (12 bytes, one 12-byte load per tap) and
+// stores 16 bytes per colour plane.
+__global__ __launch_bounds__(256) void resample_v3_kernel(const unsigned char* __restrict__ tmp, int tstride, int ow, int oh, int shift,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int vertical,
+                                                          unsigned char* __restrict__ dst_hwc, float* __restrict__ dst_chw, float m0, float m1,
+                                                          float m2, float s0, float s1, float s2) {
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (4 * q >= ow || yy >= oh) return;
+    unsigned v[12];
+    if (vertical) {
+        const int y0 = bounds[2 * yy] - shift, n = bounds[2 * yy + 1];
+        const int* k = kk + (size_t)yy * ksize;
+        int ss[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ss[i] = 1 << (PRECISION_BITS - 1);
+        const unsigned char* p = tmp + (size_t)y0 * tstride + 12 * q;
+        for (int t = 0; t < n; ++t, p += tstride) {
+            const int kv = k[t];
+            const unsigned d0 = ((const unsigned*)p)[0], d1 = ((const unsigned*)p)[1], d2 = ((const unsigned*)p)[2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                ss[b] += (int)((d0 >> (8 * b)) & 255u) * kv;
+                ss[4 + b] += (int)((d1 >> (8 * b)) & 255u) * kv;
+                ss[8 + b] += (int)((d2 >> (8 * b)) & 255u) * kv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = clip8(ss[i]);
+    } else {
+        const unsigned* p = (const unsigned*)(tmp + (size_t)yy * tstride + 12 * q);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = (p[i >> 2] >> (8 * (i & 3))) & 255u;
+    }
+    const int nv = min(4, ow - 4 * q);
+    if (dst_hwc) {
+        unsigned char* o = dst_hwc + ((size_t)yy * ow + 4 * q) * 3;
+        if (nv == 4 && (ow & 3) == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) ((unsigned*)o)[d] = v[4 * d] | (v[4 * d + 1] << 8) | (v[4 * d + 2] << 16) | (v[4 * d + 3] << 24);
+        } else {
+            for (int i = 0; i < 3 * nv; ++i) o[i] = (unsigned char)v[i];
+        }
+    }
+    if (dst_chw) {
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float* o = dst_chw + ((size_t)c * oh + yy) * ow + 4 * q;
+            f32x4 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = ((float)v[3 * j + c] / 255.0f - mean[c]) / stdv[c];
+            if (nv == 4 && (ow & 3) == 0) *(f32x4*)o = f;
+            else for (int j = 0; j < nv; ++j) o[j] = f[j];
+        }
+    }
+}
+
 constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct IngestPlan {
     int rh, rw;                 // size after the box reduction
+    int tstride;                // bytes per row of the 8-bit intermediate image
     size_t reduced, tmp, total; // workspace offsets
 };
 
@@ -213,7 +318,9 @@ int plan_ingest(int h, int w, int c, int fx, int fy, int out_w, int out_h, Inges
     p.rw = (w + fx - 1) / fx;
     size_t off = 0;
     p.reduced = off; off += (fx > 1 || fy > 1) ? align_up((size_t)p.rh * p.rw * c) : 0;
-    p.tmp = off; off += align_up((size_t)p.rh * out_w * c);           // upper bound: every reduced row
+    p.tstride = (12 * ((out_w + 3) / 4) + 15) / 16 * 16;             // RGB fast path: padded rows (>= out_w * c for c <= 3)
+    if (p.tstride < out_w * c) p.tstride = out_w * c;
+    p.tmp = off; off += align_up((size_t)p.rh * p.tstride);           // upper bound: every reduced row
     p.total = off + ALIGN;
     return GDT_OK;
 }
@@ -237,20 +344,39 @@ int run_ingest(const unsigned char* src, int h, int w, int fx, int fy, const flo
     int first = 0, rows = ch;
     if (need_v) { first = kv.first; rows = kv.last - kv.first; }
     const unsigned char* vin = cur;
-    int shift = 0;
+    int shift = 0, vstride = cw * C;
+    const bool src_aligned = ((uintptr_t)cur & 3) == 0;
     if (need_h) {
         rc = axis_coeffs(cw, box[0], box[2], out_w, stream, kh);
         if (rc != GDT_OK) return rc;
         unsigned char* tmp = (unsigned char*)(ws + p.tmp);
-        hipLaunchKernelGGL(resample_h_kernel<C>, dim3((out_w + 63) / 64, (rows + 3) / 4), dim3(256), 0, stream, cur, tmp, cw, first, rows, out_w,
-                           kh.bounds, kh.kk, kh.ksize);
+        // span of source columns behind 64 output columns: 64 * scale + 2 * support (+ rounding)
+        const double scale = ((double)box[2] - box[0]) / out_w;
+        const bool fast_h = C == 3 && src_aligned && kh.ksize <= H_MAXK && (64.0 * scale + kh.ksize + 4) * 3 <= HSPAN;
+        if (fast_h) {
+            hipLaunchKernelGGL(resample_h3_kernel, dim3((out_w + 63) / 64, (rows + H_ROWS - 1) / H_ROWS), dim3(256), 0, stream, cur,
+                               (size_t)ch * cw * 3, tmp, p.tstride, cw, first, rows, out_w, kh.bounds, kh.kk, kh.ksize);
+            vstride = p.tstride;
+        } else {
+            hipLaunchKernelGGL(resample_h_kernel<C>, dim3((out_w + 63) / 64, (rows + 3) / 4), dim3(256), 0, stream, cur, tmp, cw, first, rows, out_w,
+                               kh.bounds, kh.kk, kh.ksize);
+            vstride = out_w * C;
+        }
         vin = tmp;
         shift = first;
     }
     float m[4] = {0, 0, 0, 0}, s[4] = {1, 1, 1, 1};
     for (int i = 0; i < C; ++i) { if (mean) m[i] = mean[i]; if (stdv) s[i] = stdv[i]; }
-    hipLaunchKernelGGL(resample_v_kernel<C>, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(256), 0, stream, vin, out_w, out_h, shift, kv.bounds,
-                       kv.kk, kv.ksize, need_v ? 1 : 0, dst_hwc, dst_chw, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3]);
+    const bool fast_v = C == 3 && (vstride & 3) == 0 && ((uintptr_t)vin & 3) == 0 && vstride >= 12 * ((out_w + 3) / 4) &&
+                        (!dst_hwc || ((uintptr_t)dst_hwc & 3) == 0) && (!dst_chw || ((uintptr_t)dst_chw & 15) == 0);
+    if (fast_v) {
+        hipLaunchKernelGGL(resample_v3_kernel, dim3(((out_w + 3) / 4 + 63) / 64, (out_h + 3) / 4), dim3(256), 0, stream, vin, vstride, out_w, out_h,
+                           shift, kv.bounds, kv.kk, kv.ksize, need_v ? 1 : 0, dst_hwc, dst_chw, m[0], m[1], m[2], s[0], s[1], s[2]);
+    } else {
+        GDT_REQUIRE(vstride == out_w * C, "ingest: internal stride mismatch");
+        hipLaunchKernelGGL(resample_v_kernel<C>, dim3((out_w + 63) / 64, (out_h + 3) / 4), dim3(256), 0, stream, vin, out_w, out_h, shift, kv.bounds,
+                           kv.kk, kv.ksize, need_v ? 1 : 0, dst_hwc, dst_chw, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3]);
+    }
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
