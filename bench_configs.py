@@ -110,6 +110,7 @@ def main():
                  "initialize": False,
                  "runtime": {"wrappers": "cirfaketuplebatch",
                              "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+        gen_c, emb_c = json.loads(json.dumps(gen_p)), json.loads(json.dumps(emb_p))      # initialize_network consumes its params
         chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_p, "embed": emb_p},
                                      dev).eval()
         chain.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance"))
@@ -119,9 +120,8 @@ def main():
         out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1)}
         # the same chain with the reference's CLAHE step between generator and embedder (finetune.yml:13: wrappers
         # meanstd_post, clahepost -- post-processing runs in reverse order: CLAHE first, then the ImageNet mean / std)
-        gen_c = json.loads(json.dumps(gen_p))
         gen_c["runtime"]["wrappers"] += ",clahepost:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:1.0"
-        chain_c = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_c, "embed": emb_p},
+        chain_c = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_c, "embed": emb_c},
                                        dev).eval()
         chain_c.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance"))
         chain_c.networks["embed"].model.load_state_dict(synth.resnet101_state(0))
@@ -134,6 +134,15 @@ def main():
         r, ms = rate(lambda: clahe.clahe_lab(y, 1.0, 8, pair, pair), 128, steps=50, warmup=5)
         out["next_clahe_post_128x256"] = {"images_per_s": r, "us": round(128 / r * 1e6, 1), "hbm_GBps_algorithmic": round(38 * 65536 * r / 1e9, 1)}
         del chain_c, y
+        # "next" row: ingest of one decoded 1200x1600 photo -> thumbnail 1024 -> CLAHE -> normalised CHW
+        from gandtr_amd import ingest
+        import numpy as np
+        photo = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1200, 1600, 3)).astype(np.uint8)).to(dev)
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        r, ms = rate(lambda: ingest.ingest(photo, 1024, mean, std), 1, steps=200, warmup=10)
+        r2, _ = rate(lambda: ingest.ingest(photo, 1024, mean, std, clahe_clip=1.0), 1, steps=200, warmup=10)
+        out["next_ingest_1200x1600_to_1024"] = {"images_per_s": r, "us": round(1e6 / r, 1), "with_clahe_images_per_s": r2,
+                                                "with_clahe_us": round(1e6 / r2, 1)}
         # "next" row: retrieval scoring, revisitop-style: 200k database x 70 queries, D = 2048
         from gandtr_amd import retrieval
         import numpy as np

@@ -20,7 +20,8 @@ def _workspace(lib, n, h, w, tiles_x, tiles_y, device):
 def _float3(v):
     if v is None:
         return None
-    vals = [float(t) for t in torch.as_tensor(v).reshape(-1).tolist()]
+    flat = isinstance(v, (list, tuple)) and all(isinstance(t, (int, float)) for t in v)
+    vals = [float(t) for t in (v if flat else torch.as_tensor(v).reshape(-1).tolist())]
     if len(vals) == 1:
         vals = vals * 3
     if len(vals) != 3:

@@ -243,7 +243,8 @@ class ClahePost(Wrapper):
     def __init__(self, meanstd, clip_limit=4, grid_size=8, colorspace="lab", *, device):
         super().__init__(device)
         from .transform import ImageClahe
-        self.meanstd = [MeanStdPost.mean2tensor(x, device) for x in json.loads(meanstd)]
+        self.raw = json.loads(meanstd)                   # host copies for the HIP route (no device -> host sync per call)
+        self.meanstd = [MeanStdPost.mean2tensor(x, device) for x in self.raw]
         self.clahe = ImageClahe(clip_limit=float(clip_limit), grid_size=int(grid_size), colorspace=colorspace)
 
     def postprocess(self, tensor, outputmodel, meta):
@@ -255,7 +256,7 @@ class ClahePost(Wrapper):
             if self.clahe.colorspace.lower() != "lab":
                 raise NotImplementedError("Colorspace %s is not supported on the HIP path" % self.clahe.colorspace)
             from ... import clahe
-            pair = (self.meanstd[0], self.meanstd[1])
+            pair = (self.raw[0], self.raw[1])
             batch = tensor if tensor.dim() == 4 else tensor[None]
             out = clahe.clahe_lab(batch, self.clahe.clip_limit, self.clahe.grid_size, pair, pair)
             return out if tensor.dim() == 4 else out[0]
