@@ -27,6 +27,71 @@ GEN_GFLOP_PER_IMAGE = 99.10     # SURVEY.md section 8d (conv MACs x 2, hooks on 
 R101_GFLOP_PER_IMAGE = 326.0
 
 
+class ClockSampler:
+    """Samples the engine clock and socket power of the GPU this rank runs on (sysfs hwmon of the amdgpu driver: freq1_input,
+    power1_input) every 10 ms on a background thread.  Context for the roofline: these parts run far below the 2.4 GHz the
+    2.5 PFLOP/s peak assumes once the matrix pipes are busy.  Measurement aid only: absent files => no numbers."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        self.paths = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            prop = torch.cuda.get_device_properties(dev)
+            want = "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+            for ue in glob.glob("/sys/class/drm/card*/device/uevent"):
+                with open(ue) as f:
+                    if ("pci_slot_name=" + want) not in f.read().lower():
+                        continue
+                hw = glob.glob(os.path.join(os.path.dirname(ue), "hwmon", "hwmon*"))
+                if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                    self.paths = (os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], "power1_input"),
+                                  os.path.join(hw[0], "power1_cap"))
+                break
+        except Exception:                                  # noqa: BLE001 - measurement aid
+            self.paths = None
+        self._threading = threading
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            f, p = self._read(self.paths[0]), self._read(self.paths[1])
+            if f is not None:
+                self.samples.append((f / 1e6, (p or 0.0) / 1e6))
+            time.sleep(0.01)
+
+    def __enter__(self):
+        if self.paths:
+            self._thread = self._threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        mhz = sorted(s[0] for s in self.samples)
+        watts = [s[1] for s in self.samples]
+        cap = self._read(self.paths[2])
+        return {"sclk_mhz_mean": round(sum(mhz) / len(mhz), 1), "sclk_mhz_median": round(mhz[len(mhz) // 2], 1),
+                "sclk_mhz_min": round(mhz[0], 1), "power_w_mean": round(sum(watts) / len(watts), 1),
+                "power_cap_w": round(cap / 1e6, 1) if cap else None, "samples": len(mhz)}
+
+
 def timed(fn, steps, warmup, dev, distributed):
     for _ in range(warmup):
         fn()
@@ -183,7 +248,12 @@ def main():
     gsd = synth.generator_state(0, "instance", gain=0.02)
     gen = engine.build_generator(gsd, dev)
     xg = synth.synth_input(1000 + rank, (a.gen_batch, 3, 256, 256), 1.0).to(dev)
-    dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
+    sampler = ClockSampler(dev) if rank == 0 else None
+    if sampler is not None:
+        with sampler:
+            dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
+    else:
+        dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
     mfma_only = None
     if rank == 0:          # sustained rate of the matrix pipe alone on this very device, measured right after the timed region
         try:
@@ -202,6 +272,14 @@ def main():
         # kernel against that
         roof["mfma_only_sustained"] = mfma_only
         roof["frac_of_mfma_only"] = round(roof["achieved"] / mfma_only, 4)
+    clocks = sampler.summary() if sampler is not None else None
+    if roof is not None and clocks:
+        # the engine clock the timed region actually ran at (power-limited), the MFMA peak at that clock (peak scales with sclk:
+        # 2.5 PFLOP/s is quoted at 2.4 GHz), and the dominant kernel against it
+        roof["clocks_during_timed_region"] = clocks
+        peak_at = PEAK_F16_TFLOPS * clocks["sclk_mhz_mean"] / 2400.0
+        roof["peak_at_measured_sclk"] = round(peak_at, 1)
+        roof["frac_at_measured_sclk"] = round(roof["achieved"] / peak_at, 4) if peak_at > 0 else None
     gen_tflops = gen_ips * GEN_GFLOP_PER_IMAGE / 1e3 / world
     del gen
     torch.cuda.empty_cache()
