@@ -1,4 +1,4 @@
-"""dev tool: aggregate a tools_dump_ops.py log by (kind, kernel variant)"""
+"""dev tool: aggregate a tools/dump_ops.py log by (kind, kernel variant)"""
 import re, sys, collections
 rows = [l.split() for l in open(sys.argv[1]) if re.match(r'^\s*\d+ (conv|inorm|maxpool|gem|input)', l)]
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])

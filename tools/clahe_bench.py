@@ -1,5 +1,5 @@
 """dev tool: throughput of the CLAHE post-processing launches (gandtr_amd/csrc/clahe.hip) against the HBM roofline.
-usage: tools_clahe_bench.py [N H W] [iters]   -- prints one JSON line; algorithmic bytes = 38 B / pixel (clahe.hip header)"""
+usage: tools/clahe_bench.py [N H W] [iters]   -- prints one JSON line; algorithmic bytes = 38 B / pixel (clahe.hip header)"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -1,5 +1,5 @@
 """dev tool: throughput of the ingest launches (gandtr_amd/csrc/ingest.hip) against the HBM roofline, Pillow + numpy timed beside.
-usage: tools_ingest_bench.py [H W imsize] [iters] [--clahe]"""
+usage: tools/ingest_bench.py [H W imsize] [iters] [--clahe]"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

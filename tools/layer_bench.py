@@ -1,5 +1,5 @@
 """dev tool: sustained timing of ONE conv layer through the C ABI (power-throttled steady state, unlike the per-op event
-profile of tools_dump_ops.py).  usage: tools_layer_bench.py cin cout k stride H W N [res] [relu] [iters]"""
+profile of tools/dump_ops.py).  usage: tools/layer_bench.py cin cout k stride H W N [res] [relu] [iters]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
