@@ -74,6 +74,23 @@ def test_hub_transform_chain_with_clahe(cuda_device):
     assert float((diff > 2e-3).mean()) < 2e-3 and float(diff.max()) < 0.2      # CLAHE tolerance of tests/test_hip_clahe.py, in 1/std units
 
 
+def test_ingest_many_matches_one_by_one(cuda_device):
+    """mixed sizes on concurrent streams == the same images one by one (bitwise), in input order"""
+    rng = np.random.default_rng(9)
+    shapes = [(600, 800), (333, 500), (1200, 1600), (500, 375), (768, 1024), (2001, 1333), (97, 400), (640, 640), (1024, 683)]
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).to(cuda_device) for h, w in shapes]
+    one = [ingest.ingest(im, 362, MEAN, STD) for im in imgs]
+    many = ingest.ingest_many(imgs, 362, MEAN, STD, streams=4)
+    assert len(many) == len(one)
+    for a, b in zip(one, many):
+        assert a.shape == b.shape and torch.equal(a, b)
+    again = ingest.ingest_many(imgs, 362, MEAN, STD, clahe_clip=1.0, streams=3)
+    ref = [ingest.ingest(im, 362, MEAN, STD, clahe_clip=1.0) for im in imgs]
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+    assert ingest.ingest_many([], 362, MEAN, STD) == []
+
+
 def test_argument_errors(cuda_device):
     with pytest.raises(ValueError):
         ingest.imresize(torch.zeros(8, 8, 3), 4)                                        # not on the device

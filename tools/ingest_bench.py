@@ -49,4 +49,17 @@ try:
                            "sample": "Pillow thumbnail + numpy totensor/normalize (no CLAHE), %d images" % n}
 except ImportError:
     pass
+# a mixed-size set on concurrent streams (what a dataset pass looks like)
+rng = np.random.default_rng(3)
+sizes = [(1200, 1600), (1600, 1200), (1024, 768), (768, 1024), (1333, 2000), (2000, 1333), (960, 1280), (1500, 1500)] * 8
+photos = [torch.from_numpy(rng.integers(0, 256, (hh, ww, 3)).astype(np.uint8)).to(dev) for hh, ww in sizes]
+for nstreams in (1, 4, 8):
+    for _ in range(2):
+        ingest.ingest_many(photos, s, mean, std, clahe_clip=clip, streams=nstreams)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ingest.ingest_many(photos, s, mean, std, clahe_clip=clip, streams=nstreams)
+    torch.cuda.synchronize()
+    out["mixed_64_images_per_s_streams_%d" % nstreams] = round(5 * len(photos) / (time.perf_counter() - t0), 1)
 print(json.dumps(out))
