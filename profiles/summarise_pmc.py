@@ -16,6 +16,9 @@ def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
     m = re.search(r"(conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
+        g = re.search(r"(clahe_\w+_kernel|resample_\w+_kernel|reduce_kernel)(<[^>]*>)?", name)      # section-8f rows
+        if g:
+            return g.group(1) + (g.group(2) or "")
         return re.sub(r"^_ZN\d+_GLOBAL__N_\d+", "", name)[:48]
     base, args = m.group(1), m.group(2)
     if not args:
