@@ -1,6 +1,6 @@
 """Developer tool: per-op timing table (HIP events inside the library) for the generator / embedders on one GPU."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.getcwd())
 import torch
 from gandtr_amd import engine
 from gandtr_amd.tools import synth
