@@ -57,6 +57,9 @@ SIGNATURES = {
     "gdt_ingest_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_ingest_resize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_void_p, c_void_p,
                                      POINTER(c_float), POINTER(c_float), c_void_p, c_size_t, c_void_p]),
+    "gdt_whiten_learn_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "gdt_whiten_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int),
+                                 c_void_p, c_size_t, c_void_p]),
     "gdt_clahe_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_clahe_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gdt_clahe_lab_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_float),

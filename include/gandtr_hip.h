@@ -188,6 +188,19 @@ int gdt_ingest_resize_u8(const unsigned char* src, int h, int w, int c, int fx, 
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Learned whitening ("next" row of SURVEY.md section 8f, rank 4): the {m, P} that gdt_whiten applies
+ * Replaces  whitenlearn(X, qidxs, pidxs)  (mdir/external/cirtorch/utils/whiten.py:37-70; called with float64 D x N values from
+ * mdir/stages/whiten.py:30-75).  x: [n_vec][d] fp32 descriptor rows (device), qidx / pidx: int32 [n_pairs] (device) row numbers of
+ * the matching query / positive pairs.  All arithmetic in float64.  Outputs (device): m [d], P [d][d] row-major, eig [d] (may be
+ * NULL) = eigenvalues in decreasing order.  info (host, may be NULL): info[0] = diagonal-jitter steps of the Cholesky
+ * (whiten.py:55-70), info[1] = Jacobi sweeps.  The call synchronises the stream (convergence checks).  Rows of P are defined up
+ * to sign (eigenvectors).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int gdt_whiten_learn_workspace_bytes(int n_vec, int d, int n_pairs, size_t* bytes);
+int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec, int d, int n_pairs, double* m_out, double* p_out,
+                     double* eig_out, int* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): sustained rate of the matrix pipe alone on this device -- a kernel of nothing
  * but v_mfma_f32_32x32x16_f16 on random fp16 operands (8 independent accumulators per wave, 8 waves per CU) run for about
  * `millis` milliseconds.  bench.py reports it next to the 2.5 PFLOP/s datasheet peak: these boxes throttle to 1.5-1.7 PFLOP/s
