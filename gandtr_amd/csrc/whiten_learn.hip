@@ -128,16 +128,28 @@ __global__ __launch_bounds__(256) void add_diag_copy_kernel(const double* __rest
     const int r = (int)(i / d), c = (int)(i % d);
     a[i] = s[i] + (r == c ? alpha : 0.0);
 }
-// X = L^-1 (lower triangular), one row per step: X[k][j] = (delta_kj - sum_{t<k} L[k][t] X[t][j]) / L[k][k]
-__global__ __launch_bounds__(256) void tri_inverse_row_kernel(const double* __restrict__ l, double* __restrict__ x, int d, int k) {
+// X = L^-1 (lower triangular), one row per step: X[k][j] = (delta_kj - sum_{j<=t<k} L[k][t] X[t][j]) / L[k][k].  The sum over t is
+// split into TRI_PARTS fixed chunks (one workgroup each, partial sums in `part`), combined in chunk order by the second kernel.
+constexpr int TRI_PARTS = 16;
+__global__ __launch_bounds__(256) void tri_inverse_partial_kernel(const double* __restrict__ l, const double* __restrict__ x,
+                                                                  double* __restrict__ part, int d, int k) {
+    const int j = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (j >= d) return;
+    const int len = (k + TRI_PARTS - 1) / TRI_PARTS, t0 = max(c * len, j), t1 = min((c + 1) * len, k);     // X[t][j] = 0 for t < j
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) s += l[(size_t)k * d + t] * x[(size_t)t * d + j];
+    part[(size_t)c * d + j] = s;
+}
+__global__ __launch_bounds__(256) void tri_inverse_finish_kernel(const double* __restrict__ l, double* __restrict__ x,
+                                                                 const double* __restrict__ part, int d, int k) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d) return;
-    double s = (j == k) ? 1.0 : 0.0;
+    double s = 0.0;
     if (j <= k) {
-        for (int t = j; t < k; ++t) s -= l[(size_t)k * d + t] * x[(size_t)t * d + j];     // X[t][j] = 0 for t < j
+        s = (j == k) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < TRI_PARTS; ++c) s -= part[(size_t)c * d + j];
         s /= l[(size_t)k * d + k];
-    } else {
-        s = 0.0;
     }
     x[(size_t)k * d + j] = s;
 }
@@ -314,7 +326,10 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
         if (jitter_steps > 40) { gdt_set_error("whiten_learn: matrix is not positive definite"); return GDT_ERR_INVALID; }
     }
     // P0 = L^-1
-    for (int k = 0; k < d; ++k) hipLaunchKernelGGL(tri_inverse_row_kernel, dim3((d + 255) / 256), dim3(256), 0, st, Lm, P0, d, k);
+    for (int k = 0; k < d; ++k) {
+        hipLaunchKernelGGL(tri_inverse_partial_kernel, dim3((d + 255) / 256, TRI_PARTS), dim3(256), 0, st, Lm, P0, T1, d, k);      // T1: scratch
+        hipLaunchKernelGGL(tri_inverse_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, st, Lm, P0, T1, d, k);
+    }
 
     // C = sum (x - m)(x - m)^T over ALL vectors; D = P0 C P0^T
     Operand ce = {}; ce.kind = SRC_CENT; ce.x = x; ce.xd = d; ce.mean = m_out;
