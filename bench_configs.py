@@ -143,6 +143,17 @@ def main():
         r2, _ = rate(lambda: ingest.ingest(photo, 1024, mean, std, clahe_clip=1.0), 1, steps=200, warmup=10)
         out["next_ingest_1200x1600_to_1024"] = {"images_per_s": r, "us": round(1e6 / r, 1), "with_clahe_images_per_s": r2,
                                                 "with_clahe_us": round(1e6 / r2, 1)}
+        # "next" row: learned whitening, D = 2048, 20 k vectors, 8 k pairs (float64)
+        from gandtr_amd import whiten_learn
+        gq = torch.Generator(device=dev).manual_seed(0)
+        desc = torch.nn.functional.normalize(torch.randn(20000, 2048, generator=gq, device=dev) *
+                                             torch.linspace(1.5, 0.2, 2048, device=dev)[None, :], dim=1)
+        qi = torch.randint(0, 10000, (8000,), generator=torch.Generator().manual_seed(1))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        whiten_learn.whitenlearn(desc.t(), qi, qi + 10000)
+        torch.cuda.synchronize()
+        out["next_whiten_learn_d2048_20k_vectors"] = {"seconds": round(time.perf_counter() - t0, 3)}
+        del desc
         # "next" row: retrieval scoring, revisitop-style: 200k database x 70 queries, D = 2048
         from gandtr_amd import retrieval
         import numpy as np
