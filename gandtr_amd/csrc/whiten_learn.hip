@@ -227,14 +227,15 @@ __global__ __launch_bounds__(256) void identity_kernel(double* __restrict__ v, i
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)d * d) v[i] = (i / d == i % d) ? 1.0 : 0.0;
 }
-// eigenvalues = diag(A); order[i] = index of the i-th largest (ties by index): O(d^2) ranking, d <= a few thousand
-__global__ __launch_bounds__(256) void rank_desc_kernel(const double* __restrict__ a, int d, int* __restrict__ order, double* __restrict__ eig) {
+// values a[i * stride] (the diagonal of A: stride d + 1); order[i] = index of the i-th largest (ties by index): O(d^2) ranking, d <= a few thousand
+__global__ __launch_bounds__(256) void rank_desc_kernel(const double* __restrict__ a, size_t stride, int d, int* __restrict__ order,
+                                                        double* __restrict__ eig) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d) return;
-    const double li = a[(size_t)i * d + i];
+    const double li = a[(size_t)i * stride];
     int rank = 0;
     for (int j = 0; j < d; ++j) {
-        const double lj = a[(size_t)j * d + j];
+        const double lj = a[(size_t)j * stride];
         rank += (lj > li) || (lj == li && j < i);
     }
     order[rank] = i;
@@ -246,6 +247,74 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restri
     if (i >= (size_t)d * d) return;
     const int k = (int)(i / d), c = (int)(i % d);
     vs[i] = v[(size_t)k * d + order[c]];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- one-sided Jacobi
+// With C = Lc Lc^T the matrix D = P0 C P0^T is G G^T for G = P0 Lc, so the eigenvectors of D are the left singular vectors of G and
+// the eigenvalues the squared singular values: Hestenes' one-sided Jacobi orthogonalises the COLUMNS of G by plane rotations.  gt
+// holds G transposed (row i = column i of G, contiguous).  One workgroup per pair: both columns (2 x d doubles) sit in LDS between
+// the dot products and the rotation, so a round moves the matrix once (the two-sided form below moves A and V three times).
+__global__ __launch_bounds__(256) void hestenes_round_kernel(double* __restrict__ gt, int d, int r, int* __restrict__ changed, double tol2) {
+    extern __shared__ double cols[];                 // [2][d]
+    __shared__ double part[3][4];
+    int p, q;
+    pair_of(d, r, blockIdx.x, p, q);
+    double* rp = gt + (size_t)p * d;
+    double* rq = gt + (size_t)q * d;
+    double a = 0.0, b = 0.0, g = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const double x = rp[j], y = rq[j];
+        cols[j] = x; cols[d + j] = y;
+        a = fma(x, x, a); b = fma(y, y, b); g = fma(x, y, g);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); g += __shfl_xor(g, m); }      // fixed butterfly order
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; part[2][threadIdx.x >> 6] = g; }
+    __syncthreads();
+    a = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    b = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    g = (part[2][0] + part[2][1]) + (part[2][2] + part[2][3]);
+    if (!(g * g > tol2 * a * b)) return;             // already orthogonal to working precision (uniform across the workgroup)
+    if (threadIdx.x == 0) *changed = 1;
+    const double zeta = (b - a) / (2.0 * g);
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const double x = cols[j], y = cols[d + j];
+        rp[j] = c * x - s * y;
+        rq[j] = s * x + c * y;
+    }
+}
+// lam[i] = |row i|^2 (one workgroup per row, fixed reduction order)
+__global__ __launch_bounds__(256) void row_norm2_kernel(const double* __restrict__ gt, int d, double* __restrict__ lam) {
+    __shared__ double part[4];
+    const double* row = gt + (size_t)blockIdx.x * d;
+    double a = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) a = fma(row[j], row[j], a);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) lam[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// us[k][i] = gt[order[i]][k] / sqrt(lam[order[i]]): unit left singular vectors as columns, in eigenvalue order
+__global__ __launch_bounds__(256) void unit_columns_kernel(const double* __restrict__ gt, const double* __restrict__ lam,
+                                                           const int* __restrict__ order, double* __restrict__ us, int d) {
+    __shared__ double tile[32][33];
+    const int i0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31;
+    for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+        const int i = i0 + r, k = k0 + tx;
+        if (i < d && k < d) { const int src = order[i]; tile[r][tx] = gt[(size_t)src * d + k] / sqrt(lam[src]); }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+        const int k = k0 + r, i = i0 + tx;
+        if (i < d && k < d) us[(size_t)k * d + i] = tile[tx][r];
+    }
+}
+__global__ __launch_bounds__(256) void zero_upper_kernel(double* __restrict__ a, int d) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)d * d && (int)(i % d) > (int)(i / d)) a[i] = 0.0;
 }
 
 constexpr size_t ALIGN = 256;
@@ -262,6 +331,21 @@ int plan(int n_vec, int d, int n_pairs, Layout& L) {
     L.flag = off; off += ALIGN; L.red = off; off += ALIGN;
     L.order = off; off += align_up((size_t)d * sizeof(int));
     L.total = off + ALIGN;
+    return GDT_OK;
+}
+
+// in-place right-looking Cholesky of the lower triangle of `a`; failed = 1 when a pivot is not positive (synchronises the stream)
+int cholesky_inplace(hipStream_t st, double* a, int d, int* flag, int& failed) {
+    GDT_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    for (int k = 0; k < d; ++k) {
+        hipLaunchKernelGGL(chol_column_kernel, dim3((d - k - 1 + 255) / 256 + (k == d - 1 ? 1 : 0)), dim3(256), 0, st, a, d, k, flag);
+        if (k + 1 < d)
+            hipLaunchKernelGGL(chol_update_kernel, dim3((d - k - 1 + 63) / 64, (d - k - 1 + 3) / 4), dim3(256), 0, st, a, d, k, flag);
+    }
+    hipLaunchKernelGGL(chol_diag_kernel, dim3((d + 255) / 256), dim3(256), 0, st, a, d);
+    failed = 0;
+    GDT_CHECK_HIP(hipMemcpyAsync(&failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    GDT_CHECK_HIP(hipStreamSynchronize(st));
     return GDT_OK;
 }
 
@@ -310,16 +394,9 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
     int jitter_steps = 0;
     for (;;) {
         hipLaunchKernelGGL(add_diag_copy_kernel, dim3(dd_blocks), dim3(256), 0, st, S, Lm, d, alpha);
-        GDT_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-        for (int k = 0; k < d; ++k) {
-            hipLaunchKernelGGL(chol_column_kernel, dim3((d - k - 1 + 255) / 256 + (k == d - 1 ? 1 : 0)), dim3(256), 0, st, Lm, d, k, flag);
-            if (k + 1 < d)
-                hipLaunchKernelGGL(chol_update_kernel, dim3((d - k - 1 + 63) / 64, (d - k - 1 + 3) / 4), dim3(256), 0, st, Lm, d, k, flag);
-        }
-        hipLaunchKernelGGL(chol_diag_kernel, dim3((d + 255) / 256), dim3(256), 0, st, Lm, d);
         int failed = 0;
-        GDT_CHECK_HIP(hipMemcpyAsync(&failed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        GDT_CHECK_HIP(hipStreamSynchronize(st));
+        rc = cholesky_inplace(st, Lm, d, flag, failed);
+        if (rc != GDT_OK) return rc;
         if (!failed) break;
         alpha = alpha == 0.0 ? 1e-10 : alpha * 10.0;
         ++jitter_steps;
@@ -335,33 +412,56 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
     Operand ce = {}; ce.kind = SRC_CENT; ce.x = x; ce.xd = d; ce.mean = m_out;
     gemm(st, ce, ce, T1, d, d, n_vec, 1.0);                                                    // T1 = C (symmetric)
     hipLaunchKernelGGL(transpose_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st, P0, T2, d);      // T2 = P0^T  ([k][i] = P0[i][k])
-    gemm(st, mat(T2, d), mat(T1, d), A, d, d, d, 1.0);                                         // A = P0 C        (sum_k P0[i][k] C[k][j])
-    hipLaunchKernelGGL(transpose_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st, A, T1, d);       // T1 = (P0 C)^T
-    gemm(st, mat(T1, d), mat(T2, d), A, d, d, d, 1.0);                                         // A = (P0 C) P0^T (sum_k (P0C)[i][k] P0[j][k])
-
-    hipLaunchKernelGGL(symmetrise_kernel, dim3(dd_blocks), dim3(256), 0, st, A, d);
-    // eigen-decomposition of the symmetric A: cyclic Jacobi, V accumulates the rotations
-    hipLaunchKernelGGL(identity_kernel, dim3(dd_blocks), dim3(256), 0, st, V, d);
+    // preferred: one-sided Jacobi on G = P0 Lc (needs C positive definite and both columns of a pair in LDS)
     int sweeps = 0;
-    for (; sweeps < 40; ++sweeps) {
-        hipLaunchKernelGGL(offdiag_kernel, dim3(1), dim3(1024), 0, st, A, d, red);
-        double h[2];
-        GDT_CHECK_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
-        GDT_CHECK_HIP(hipStreamSynchronize(st));
-        if (!(h[0] > 1e-26 * h[1])) break;                                                     // off-diagonal norm below 1e-13 of the diagonal's
-        for (int r = 0; r < d - 1; ++r) {
-            hipLaunchKernelGGL(jacobi_angles_kernel, dim3((d / 2 + 255) / 256), dim3(256), 0, st, A, d, r, cs);
-            hipLaunchKernelGGL(jacobi_rows_kernel, dim3((d + 255) / 256, d / 2), dim3(256), 0, st, A, d, r, cs);
-            hipLaunchKernelGGL(jacobi_cols_kernel, dim3(2 * d), dim3(256), (size_t)d * sizeof(double), st, A, V, d, r, cs);
-        }
+    int c_failed = 1;
+    if ((size_t)2 * d * sizeof(double) <= 64 * 1024) {
+        hipLaunchKernelGGL(add_diag_copy_kernel, dim3(dd_blocks), dim3(256), 0, st, T1, A, d, 0.0);
+        rc = cholesky_inplace(st, A, d, flag, c_failed);
+        if (rc != GDT_OK) return rc;
     }
-    // eigenvalues in decreasing order, P = eigvec^T P0
-    hipLaunchKernelGGL(rank_desc_kernel, dim3((d + 255) / 256), dim3(256), 0, st, A, d, order, eig_out);
-    hipLaunchKernelGGL(gather_cols_kernel, dim3(dd_blocks), dim3(256), 0, st, V, order, T1, d);            // T1[k][i] = V[k][order[i]]
-    gemm(st, mat(T1, d), mat(P0, d), p_out, d, d, d, 1.0);                                                  // P[i][j] = sum_k T1[k][i] P0[k][j]
+    if (!c_failed) {
+        hipLaunchKernelGGL(zero_upper_kernel, dim3(dd_blocks), dim3(256), 0, st, A, d);                        // A = Lc
+        gemm(st, mat(A, d), mat(T2, d), V, d, d, d, 1.0);                 // V = G^T: V[i][k] = sum_j Lc[j][i] P0[k][j]
+        for (; sweeps < 60; ++sweeps) {
+            GDT_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+            for (int r = 0; r < d - 1; ++r)
+                hipLaunchKernelGGL(hestenes_round_kernel, dim3(d / 2), dim3(256), (size_t)2 * d * sizeof(double), st, V, d, r, flag, 1e-28);
+            int changed = 0;
+            GDT_CHECK_HIP(hipMemcpyAsync(&changed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            GDT_CHECK_HIP(hipStreamSynchronize(st));
+            if (!changed) { ++sweeps; break; }
+        }
+        hipLaunchKernelGGL(row_norm2_kernel, dim3(d), dim3(256), 0, st, V, d, cs);                              // cs = eigenvalues (unordered)
+        hipLaunchKernelGGL(rank_desc_kernel, dim3((d + 255) / 256), dim3(256), 0, st, cs, (size_t)1, d, order, eig_out);
+        hipLaunchKernelGGL(unit_columns_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st, V, cs, order, T1, d);
+    } else {
+        // fallback (C singular, or d too large for the LDS form): two-sided cyclic Jacobi on A = P0 C P0^T, V accumulates the rotations
+        gemm(st, mat(T2, d), mat(T1, d), A, d, d, d, 1.0);                                         // A = P0 C        (sum_k P0[i][k] C[k][j])
+        hipLaunchKernelGGL(transpose_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st, A, T1, d);       // T1 = (P0 C)^T
+        gemm(st, mat(T1, d), mat(T2, d), A, d, d, d, 1.0);                                         // A = (P0 C) P0^T (sum_k (P0C)[i][k] P0[j][k])
+        hipLaunchKernelGGL(symmetrise_kernel, dim3(dd_blocks), dim3(256), 0, st, A, d);
+        hipLaunchKernelGGL(identity_kernel, dim3(dd_blocks), dim3(256), 0, st, V, d);
+        for (; sweeps < 40; ++sweeps) {
+            hipLaunchKernelGGL(offdiag_kernel, dim3(1), dim3(1024), 0, st, A, d, red);
+            double h[2];
+            GDT_CHECK_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
+            GDT_CHECK_HIP(hipStreamSynchronize(st));
+            if (!(h[0] > 1e-26 * h[1])) break;                                                     // off-diagonal norm below 1e-13 of the diagonal's
+            for (int r = 0; r < d - 1; ++r) {
+                hipLaunchKernelGGL(jacobi_angles_kernel, dim3((d / 2 + 255) / 256), dim3(256), 0, st, A, d, r, cs);
+                hipLaunchKernelGGL(jacobi_rows_kernel, dim3((d + 255) / 256, d / 2), dim3(256), 0, st, A, d, r, cs);
+                hipLaunchKernelGGL(jacobi_cols_kernel, dim3(2 * d), dim3(256), (size_t)d * sizeof(double), st, A, V, d, r, cs);
+            }
+        }
+        hipLaunchKernelGGL(rank_desc_kernel, dim3((d + 255) / 256), dim3(256), 0, st, A, (size_t)d + 1, d, order, eig_out);
+        hipLaunchKernelGGL(gather_cols_kernel, dim3(dd_blocks), dim3(256), 0, st, V, order, T1, d);            // T1[k][i] = V[k][order[i]]
+    }
+    // P = eigvec^T P0 (eigenvectors = columns of T1, eigenvalues decreasing)
+    gemm(st, mat(T1, d), mat(P0, d), p_out, d, d, d, 1.0);                                                      // P[i][j] = sum_k T1[k][i] P0[k][j]
     GDT_CHECK_HIP(hipGetLastError());
     GDT_CHECK_HIP(hipStreamSynchronize(st));
-    if (info) { info[0] = jitter_steps; info[1] = sweeps; }
+    if (info) { info[0] = jitter_steps; info[1] = c_failed ? -sweeps : sweeps; }      // negative: the two-sided fallback ran
     return GDT_OK;
 }
 

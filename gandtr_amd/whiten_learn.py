@@ -40,7 +40,8 @@ def whitenlearn(X, qidxs, pidxs, return_info=False):
                                         P.data_ptr(), eig.data_ptr(), info, ws.data_ptr(), ws.numel(),
                                         torch.cuda.current_stream(dev).cuda_stream))
     if return_info:
-        return m[:, None], P, {"eigenvalues": eig, "cholesky_jitter_steps": info[0], "jacobi_sweeps": info[1]}
+        return m[:, None], P, {"eigenvalues": eig, "cholesky_jitter_steps": info[0], "jacobi_sweeps": abs(info[1]),
+                               "one_sided": info[1] > 0}        # False: the scatter matrix was singular, two-sided fallback
     return m[:, None], P
 
 
