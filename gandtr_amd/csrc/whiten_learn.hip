@@ -6,10 +6,11 @@
 // in decreasing order;  P = eigvec^T P0.
 // Here:  the two O(d^2 N) covariance products are one tiled float64 GEMM kernel reading the float32 descriptor rows directly
 // (pair differences / mean-centred rows formed on the fly, fixed summation order => deterministic and exactly symmetric);
-// D = P0 C P0^T with C = sum (x - m)(x - m)^T, which is the same matrix without materialising the d x N product;  Cholesky and the
-// triangular inverse run as d short launches each (d <= 2048: a few tens of ms);  the symmetric eigenproblem is a parallel cyclic
-// Jacobi (round-robin pairs: d/2 disjoint rotations per round; row update coalesced over columns, column update per row through
-// LDS), converged on the off-diagonal norm.  Eigenvectors are defined up to sign, so P's rows are too.
+// with C = sum (x - m)(x - m)^T the reference's d x N product is never materialised: the matrix to decompose is P0 C P0^T = G G^T for
+// G = P0 chol(C), and its eigenpairs are the left singular vectors / squared singular values of G, found by a one-sided (Hestenes)
+// Jacobi with both columns of a pair in LDS (one pass over the matrix per round, HBM-bound at 5.9 TB/s); a two-sided cyclic Jacobi
+// on P0 C P0^T is the fallback when C is singular.  Cholesky and the triangular inverse run as d short launches each (d <= 2048: a
+// few tens of ms).  Eigenvectors are defined up to sign, so P's rows are too.
 #include <math.h>
 #include <string.h>
 
