@@ -14,8 +14,6 @@
 #include <math.h>
 #include <string.h>
 
-#include <vector>
-
 #include "../../include/gandtr_hip.h"
 #include "gdt_common.h"
 

@@ -39,6 +39,19 @@ def test_imresize_bit_exact(cuda_device, h, w, s):
     assert np.array_equal(got, np.asarray(p))
 
 
+@pytest.mark.parametrize("h,w,ow,oh", [(60, 80, 200, 150), (100, 100, 100, 37), (33, 47, 47, 33), (64, 48, 48, 200)])
+def test_plain_resize_including_enlargement(cuda_device, h, w, ow, oh):
+    """Image.resize((ow, oh), LANCZOS) without the thumbnail plan: enlargements use the unit-support filter (filterscale = 1)"""
+    a = np.random.default_rng(h * w).integers(0, 256, (h, w, 3)).astype(np.uint8)
+    got, _ = ingest.resize(torch.from_numpy(a).to(cuda_device), ow, oh)
+    assert np.array_equal(got.cpu().numpy(), I.resample_u8(a, ow, oh))
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(got.cpu().numpy(), np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS)))
+
+
 @pytest.mark.parametrize("c", [1, 2, 4])
 def test_other_channel_counts(cuda_device, c):
     a = np.random.default_rng(c).integers(0, 256, (300, 411, c)).astype(np.uint8)
