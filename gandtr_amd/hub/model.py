@@ -66,6 +66,9 @@ def _create(scenario, substitutions, pretrained, device):
     if "augmentations" not in data_params:
         data_params["augmentations"] = data_params.pop("transforms")
     network.transform = initialize_transforms(**data_params)
+    # device-side counterpart for decoded uint8 images already in HBM (no reference equivalent: SURVEY.md section 8f, ingest row)
+    from ..ingest import DeviceTransform
+    network.transform_device = DeviceTransform(**data_params)
     return network
 
 

@@ -133,3 +133,35 @@ def _stream_pool(dev, n):
     if key not in _POOLS:
         _POOLS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _POOLS[key]
+
+
+class DeviceTransform:
+    """Device-side counterpart of the ``.transform`` the hub attaches to a network (mdir/hub/model.py:38-42 builds it from
+    ``runtime.data.transforms``, e.g. ``pil2np | apply_clahe:1.0 | totensor | normalize``): takes the DECODED image as a uint8
+    H x W x 3 tensor on the device (optionally the ``imsize`` of the dataset's ``imresize``) and returns the fp32 3 x h x w tensor
+    the network expects.  Supported steps: pil2np, apply_clahe[:clip[:grid[:lab]]], totensor, normalize."""
+
+    def __init__(self, augmentations, mean_std):
+        self.mean, self.std = [float(v) for v in mean_std[0]], [float(v) for v in mean_std[1]]
+        self.clahe_clip, self.clahe_grid, self.normalize = None, 8, False
+        self.spec = augmentations
+        for step in [t.strip() for t in augmentations.split("|") if t.strip()]:
+            name, *args = step.split(":")
+            if name in ("pil2np", "totensor"):
+                continue
+            if name == "normalize":
+                self.normalize = True
+            elif name == "apply_clahe":
+                self.clahe_clip = float(args[0]) if args else 4.0          # ApplyClahe defaults (photometric_transforms.py:31)
+                self.clahe_grid = int(args[1]) if len(args) > 1 else 8
+                if len(args) > 2 and args[2].lower() != "lab":
+                    raise NotImplementedError("Colorspace %s is not supported on the HIP path" % args[2])
+            else:
+                raise KeyError("transform '%s' has no device implementation" % name)
+
+    def __call__(self, img, imsize=None):
+        mean, std = (self.mean, self.std) if self.normalize else ([0.0] * 3, [1.0] * 3)
+        return ingest(img, imsize, mean, std, self.clahe_clip, self.clahe_grid)
+
+    def __repr__(self):
+        return "%s(%s, mean=%s, std=%s)" % (type(self).__name__, self.spec, self.mean, self.std)

@@ -104,6 +104,20 @@ def test_ingest_many_matches_one_by_one(cuda_device):
     assert ingest.ingest_many([], 362, MEAN, STD) == []
 
 
+def test_hub_device_transform(cuda_device):
+    """net.transform_device(decoded uint8 image) == ingest with the network's own mean / std / CLAHE settings, and feeds the net"""
+    import hubconf
+    net = hubconf.gem_vgg16_cyclegan(pretrained=False, device=cuda_device)
+    a = np.random.default_rng(4).integers(0, 256, (300, 400, 3)).astype(np.uint8)
+    u8 = torch.from_numpy(a).to(cuda_device)
+    x = net.transform_device(u8, imsize=256)
+    assert x.shape == (3, 192, 256) and x.is_cuda
+    assert torch.equal(x, ingest.ingest(u8, 256, MEAN, STD, clahe_clip=1.0))
+    with torch.no_grad():
+        d = net(x[None])
+    assert d.shape[0] == 512 and torch.isfinite(d).all()
+
+
 def test_argument_errors(cuda_device):
     with pytest.raises(ValueError):
         ingest.imresize(torch.zeros(8, 8, 3), 4)                                        # not on the device

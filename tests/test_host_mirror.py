@@ -245,3 +245,20 @@ def test_infer_stage_contract(tmp_path):
                        ([synth.synth_input(30, (3, 32, 32), 1.0)],))
     assert len(pics) == 1 and pics[0].shape == (32, 32, 3) and 0.0 <= pics[0].min() and pics[0].max() <= 1.0
     assert infer({"network": emb, "output": {"inference": {"name": "embedding"}}}, ([],)) == ({"status": "skipped"},)
+
+
+def test_hub_networks_carry_a_device_transform():
+    """`.transform_device`: device-side counterpart of `.transform` for decoded uint8 images (ingest row of SURVEY.md section 8f)"""
+    import hubconf
+    net = hubconf.gem_vgg16_cyclegan(pretrained=False, device="cpu")
+    t = net.transform_device
+    assert t.clahe_clip == 1.0 and t.clahe_grid == 8 and t.normalize and t.mean == [0.485, 0.456, 0.406]
+    assert "apply_clahe:1.0" in repr(t)
+    g = hubconf.cyclegan(pretrained=False, device="cpu").transform_device
+    assert g.clahe_clip is None and g.mean == [0.5, 0.5, 0.5]
+    from gandtr_amd.ingest import DeviceTransform
+    import pytest
+    with pytest.raises(KeyError):
+        DeviceTransform("pil2np | random_crop:224 | totensor", [[0.5] * 3, [0.5] * 3])
+    with pytest.raises(NotImplementedError):
+        DeviceTransform("pil2np | apply_clahe:1.0:8:luv | totensor", [[0.5] * 3, [0.5] * 3])
