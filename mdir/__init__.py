@@ -33,6 +33,7 @@ _ALIASES = {
     "mdir.learning.checkpoints": "gandtr_amd.learning.checkpoints",
     "mdir.stages": "gandtr_amd.stages",
     "mdir.stages.infer": "gandtr_amd.stages.infer",
+    "mdir.stages.whiten": "gandtr_amd.stages.whiten",
     "mdir.tools": "gandtr_amd.tools",
     "mdir.tools.tensors": "gandtr_amd.tools.tensors",
     "mdir.tools.utils": "gandtr_amd.tools.utils",

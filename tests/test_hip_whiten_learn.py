@@ -88,3 +88,21 @@ def test_jitter_and_argument_errors(cuda_device):
     out = whiten_learn.learn_lw_whitening(["a%d" % i for i in range(40)], X.t().contiguous().to(cuda_device),
                                           ["a0", "a1"], ["a20", "a21"])
     assert out["P"].shape == (8, 8) and out["m"].shape == (8, 1) and out["P"].dtype == np.float64
+
+
+def test_stages_learn_then_apply(cuda_device):
+    """learn_lw_whitening -> whiten (mdir/stages/whiten.py): host formats in and out, numpy reference for the apply step"""
+    import mdir.stages.whiten as stage
+    X, q, p = _descriptors(3, 64, 800)
+    names = ["im%d" % i for i in range(X.shape[1])]
+    values = X.T.copy()                                                         # N x D, as the stage receives them
+    meta, lw = stage.learn_lw_whitening({}, (names, values, [names[i] for i in q], [names[i] for i in p]))
+    assert meta["stats"] == {"failed_times": 0, "vectors_used": 1.0, "vectors_total": len(q)} and "whitening_learn" in meta["timings"]
+    assert lw["m"].shape == (64, 1) and lw["P"].shape == (64, 64) and lw["P"].dtype == np.float64
+    m_ref, P_ref, _ = W.whitenlearn(X.astype(np.float64), q, p)
+    assert W.rows_up_to_sign(lw["P"], P_ref) < 1e-7
+    meta, names2, out = stage.whiten({"dimensions": 32}, (lw, names, values))
+    assert names2 == names and out.shape == (800, 32)
+    ref = lw["P"][:32] @ (X.astype(np.float64) - lw["m"])                       # whitenapply, cirtorch/utils/whiten.py:4-12
+    ref = (ref / (np.linalg.norm(ref, axis=0, keepdims=True) + 1e-6)).T
+    assert np.abs(out - ref).max() < 1e-4

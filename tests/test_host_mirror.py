@@ -262,3 +262,23 @@ def test_hub_networks_carry_a_device_transform():
         DeviceTransform("pil2np | random_crop:224 | totensor", [[0.5] * 3, [0.5] * 3])
     with pytest.raises(NotImplementedError):
         DeviceTransform("pil2np | apply_clahe:1.0:8:luv | totensor", [[0.5] * 3, [0.5] * 3])
+
+
+def test_whitening_stage_signatures_without_a_device():
+    """stage ABI of mdir/stages/whiten.py: (params, data) -> (metadata, *columns); the trivial branches need no device"""
+    import numpy as np
+    import pytest
+    import torch
+    import mdir.stages.whiten as stage
+    from gandtr_amd.stages import FUNCTIONS
+    assert FUNCTIONS["mdir.stages.whiten.learn_lw_whitening"] is stage.learn_lw_whitening
+    assert stage.learn_lw_whitening({}, ([], np.zeros((0, 4)), [], [])) == ({"status": "Empty whitening produced"}, None)
+    meta, names, values = stage.whiten({"dimensions": None}, (None, ["a"], np.zeros((1, 4))))
+    assert meta == {"status": "No whitening applied"} and names == ["a"]
+    with pytest.raises(AssertionError):
+        stage.whiten({"dimensions": None, "bogus": 1}, (None, [], np.zeros((0, 4))))
+    with pytest.raises(AssertionError):
+        stage.learn_lw_whitening({}, (["a"], np.zeros((2, 4)), [], []))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            stage.learn_lw_whitening({}, (["a", "b"], np.zeros((2, 4)), ["a"], ["b"]))
