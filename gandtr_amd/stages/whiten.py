@@ -18,7 +18,9 @@ def _device():
 
 
 def whiten(params, data):
-    """Apply pre-computed whitening (mdir/stages/whiten.py:10-27; whitenapply, cirtorch/utils/whiten.py:4-12)"""
+    """Apply pre-computed whitening (mdir/stages/whiten.py:10-27; whitenapply, cirtorch/utils/whiten.py:4-12).  The reference
+    multiplies in float64 on the host (numpy promotes against the float64 P); ``gdt_whiten`` works in float32 like the ``cirwhiten``
+    wrapper of the inference path (wrapper.py:320-322): unit-norm outputs agree to ~1e-6."""
     dimensions = params.pop("dimensions", None) or None
     assert not params, params.keys()
     whitening, names, values = data
