@@ -69,6 +69,28 @@ def test_identities_at_descriptor_size_512(cuda_device):
     assert torch.equal(again.cpu(), torch.from_numpy(P))                    # deterministic
 
 
+def test_identities_at_full_descriptor_size_2048(cuda_device):
+    """GeM-ResNet-101 descriptor size: the sign-free identities, checked on the device in float64"""
+    d, n = 2048, 12000
+    g = torch.Generator(device=cuda_device).manual_seed(0)
+    X = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=cuda_device) *
+                                      torch.linspace(1.5, 0.2, d, device=cuda_device)[None, :], dim=1)
+    q = torch.randint(0, n // 2, (6000,), generator=torch.Generator().manual_seed(1))
+    p = q + n // 2
+    m, P, info = whiten_learn.whitenlearn(X.t(), q, p, return_info=True)
+    assert info["one_sided"] and info["cholesky_jitter_steps"] == 0
+    Xd = X.double()
+    diff = Xd[q.to(cuda_device)] - Xd[p.to(cuda_device)]
+    S = diff.t() @ diff / len(q)
+    eye = torch.eye(d, device=cuda_device, dtype=torch.float64)
+    assert float((P @ S @ P.t() - eye).abs().max()) < 1e-8
+    Xc = Xd - m.t()
+    D = P @ (Xc.t() @ Xc) @ P.t()
+    w = info["eigenvalues"]
+    assert float((D - torch.diag(w)).abs().max()) < 1e-8 * float(w.max())
+    assert bool((w[1:] <= w[:-1]).all())
+
+
 def test_jitter_and_argument_errors(cuda_device):
     X = torch.zeros(8, 40)
     X[:4] = torch.randn(4, 40, generator=torch.Generator().manual_seed(0))  # rank-deficient covariance: needs the diagonal jitter
