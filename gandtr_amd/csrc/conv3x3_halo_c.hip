@@ -1,0 +1,501 @@
+// 3x3 / stride-1 / pad-1 convolution (and ConvTranspose2d(k3,s2,p1,op1), CT form) in the "f16c" precision mode: fp32 NHWC
+// activations, fp16 MFMA main product plus a block-scaled (MX) low-precision product that carries both rounding residuals.
+//
+// Why: single-pass fp16 (11-bit operands) leaves the 24-layer random-weight generator at 2e-3 of the fp32 reference, above
+// north_star's 1e-3; the exact split (f16x3: a_hi*w_hi + a_lo*w_hi + a_hi*w_lo, three fp16 passes) costs 3x the matrix work.
+// The two correction terms are ~2^-11 of the result, so 2-4 significant bits are enough for them:
+//     a*w  ~=  a_hi*w_hi  (v_mfma_f32_32x32x16_f16, exact products, fp32 accumulate)
+//           +  [a_lo | a_hi]_fp4 . [w_hi | w_lo]_fp6   (ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32 k-values: its two 32-wide
+//              K blocks hold the two correction terms; per-block E8M0 scales undo the 2^12 / per-block weight scaling)
+// = 1.5x the fp16 work at the fp4/fp6 MFMA rate (measured 1.43x, profiles/experiments/mx_probe.hip) instead of 3x.  Measured
+// against the fp32 oracle: <= 4e-4 at every tap of the full-size generator (single-pass fp16: 2.5e-3; f16x3: 3e-6).
+//
+// Structure = conv3x3_halo_rb.hip (persistent workgroups, 16x16 output patch x 256 output channels, 8 waves of 128 x 64,
+// LDS-resident halo, weights streamed L2 -> registers in fragment order, swapped MFMA operands D[cout][pixel]).  Differences:
+//   * the halo is read as fp32 (32 bytes per 8-channel piece), normalised / ReLU'd / residual-added in fp32 (the producer's
+//     InstanceNorm folded in, MODE bits as in the fp16 kernel), then split: fp16 hi plane (128-byte rows, same swizzle) and an
+//     fp4 plane (64-byte rows: [lo 0-31][hi 0-31][lo 32-63][hi 32-63], v_cvt_scalef32_pk_fp4_*), both written to LDS;
+//   * per tap step: 32 fp16 MFMAs + 16 MX MFMAs per wave; MX weight fragments (24 bytes per lane: lanes 0-31 w_hi, lanes 32-63 w_lo
+//     of the same 32 k-values, e2m3, block scale byte per lane) stream from L2 like the fp16 ones;
+//   * epilogue straight from the accumulators: a lane holds 4 consecutive output channels of one pixel = one 16-byte fp32
+//     store (no LDS transpose, so the two halo stages may use 126 KB of LDS); InstanceNorm statistics by a halving butterfly
+//     over the 32 pixel lanes (31 shuffles per column block), fixed order => deterministic.
+#include <cstdio>
+#include <cstdlib>
+
+#include "gdt_common.h"
+
+namespace {
+
+constexpr int ROWB = 128;          // bytes per row of the fp16 plane (64 halves of K)
+constexpr int QROWB = 64;          // bytes per row of the fp4 plane
+constexpr int HALO_W = 18;
+constexpr int PH = 16;
+constexpr int HALO_ROWS_PAD = 328;
+constexpr int A_BYTES = HALO_ROWS_PAD * ROWB;              // 41984
+constexpr int Q_BYTES = HALO_ROWS_PAD * QROWB;             // 20992
+constexpr int STAGE_BYTES = A_BYTES + Q_BYTES;             // 62976
+constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
+constexpr int BM = PH * 16;
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES;
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
+
+// MODE bits: 1 = the producer's InstanceNorm (+ReLU) is applied while staging; 2 = ... plus a residual; 4 = the transformed
+// tensor is written back.  CT: transposed form (see conv3x3_halo_rb.hip).
+template <int BN, int WGM, int WGN, int MODE, bool CT = false>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const ConvLaunch d, const int vblocks) {
+    constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
+    constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
+    constexpr int HW_ = CT ? 17 : HALO_W;
+    constexpr int HROWS = HW_ * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;
+    constexpr int NTAP = CT ? 4 : 9;
+    constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
+    // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
+    // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
+    constexpr int SLOTS = NTAP * 4, SPR = SLOTS / (NR + 1);
+    static_assert(SPR >= 1 && NR * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM == 4 && WTM == 128 && (TN == 2 || TN == 4), "tile shape (one 128-row statistics record per wave row)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const float* __restrict__ inf = (const float*)d.in;
+    const float* __restrict__ resf = (const float*)d.in_res;
+    float* __restrict__ wbf = (float*)d.in_out;
+
+    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + PH - 1) / PH;
+    const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
+    auto tile_at = [&](int vb) -> TileAt {
+        TileAt t;
+        t.valid = vb < vblocks && gdt_tile_of_block(vb, ntm, ntn, t.tile_m, t.tile_n);
+        if (!t.valid) { t.tile_m = 0; t.tile_n = 0; }
+        t.n = t.tile_m / tpi;
+        const int tr = t.tile_m - t.n * tpi;
+        t.y0 = (tr / tiles_x) * PH; t.x0 = (tr % tiles_x) << 4;
+        return t;
+    };
+    int vb = blockIdx.x;
+    TileAt cur = tile_at(vb);
+    if (!cur.valid) return;
+
+    // ---- halo loader: through registers, branch-free (see conv3x3_halo_rb.hip for why)
+    const int lrow = tid >> 3;
+    const bool refl = d.pad_reflect != 0;
+    const float lo_scale = __builtin_ldexpf(1.f, -d.c_lo_exp), hi_scale = __builtin_ldexpf(1.f, d.c_hi_exp);   // cvt divides by the scale
+    struct Pend { float4 r0, r1, s0, s1; unsigned goff; bool ok; };
+    auto load_piece = [&](const TileAt& ta, int chunk, int r) -> Pend {
+        int lr = lrow;
+        asm volatile("" : "+v"(lr));
+        const int h = min(r * RPR + lr, HROWS_PAD - 1);
+        const int hy = (h * (CT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;
+        const int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
+        int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+        int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+        ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
+        const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+        const int q = (lane & 7) ^ ((hx >> 1) & 7);
+        Pend p;
+        p.goff = ((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + 3)) + (chunk * 8 + q) * 8;      // fp32 element offset (< 2^30, checked on the host)
+        p.ok = (h < HROWS) & (inb | refl);
+        p.r0 = *(const float4*)(inf + p.goff); p.r1 = *(const float4*)(inf + p.goff + 4);
+        if (RES) { p.s0 = *(const float4*)(resf + p.goff); p.s1 = *(const float4*)(resf + p.goff + 4); }
+        return p;
+    };
+    float* nlds = (float*)(smem + 2 * STAGE_BYTES);
+    auto stage_norm = [&](const TileAt& ta, int slot) {
+        for (int i = tid; i < d.Cin / 2; i += NT) {              // float4 = 2 channels x (mean, rstd) -> (scale, shift)
+            const float4 v = *(const float4*)(d.in_norm + (long)ta.n * d.Cin * 2 + i * 4);
+            *(float4*)(nlds + slot * 512 + i * 4) = make_float4(v.y, -v.x * v.y, v.w, -v.z * v.w);
+        }
+    };
+    auto store_piece = [&](int slot, int stage_off, int r, const Pend& p) {
+        const int row = min(r * RPR + lrow, HROWS_PAD - 1);
+        const int phy = (row * (CT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
+        float a[8] = {p.r0.x, p.r0.y, p.r0.z, p.r0.w, p.r1.x, p.r1.y, p.r1.z, p.r1.w};
+        if (NORM) {
+            const int cq = (p.goff >> 3) & ((1 << d.lc8) - 1);                     // chunk * 8 + q
+            const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
+            const float lo = d.in_relu ? 0.f : -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = np4[k];
+                a[2 * k] = fmaxf(fmaf(a[2 * k], v.x, v.y), lo);
+                a[2 * k + 1] = fmaxf(fmaf(a[2 * k + 1], v.z, v.w), lo);
+            }
+            if (RES) {
+                a[0] += p.s0.x; a[1] += p.s0.y; a[2] += p.s0.z; a[3] += p.s0.w;
+                a[4] += p.s1.x; a[5] += p.s1.y; a[6] += p.s1.z; a[7] += p.s1.w;
+            }
+        }
+        // write-back of the transformed tensor (every piece stores the value of its clamped source pixel: identical bits from
+        // neighbouring patches, no branch)
+        if (WB) {
+            *(float4*)(wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
+            *(float4*)(wbf + p.goff + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = p.ok ? a[e] : 0.f;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
+        unsigned qlo = 0, qhi = 0;
+#define GDT_Q4(k)                                                                                                     \
+        {                                                                                                             \
+            const float l0 = a[2 * k] - (float)o[2 * k], l1 = a[2 * k + 1] - (float)o[2 * k + 1];                    \
+            qlo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qlo, l0, l1, lo_scale, k);                                 \
+            f16x2 hp; hp[0] = o[2 * k]; hp[1] = o[2 * k + 1];                                                         \
+            qhi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(qhi, hp, hi_scale, k);                                     \
+        }
+        GDT_Q4(0) GDT_Q4(1) GDT_Q4(2) GDT_Q4(3)
+#undef GDT_Q4
+        *(f16x8*)(smem + stage_off + row * ROWB + ((lane & 7) << 4)) = o;
+        // fp4 plane: this thread holds source chunk q (channels 8q .. 8q+7): 32-channel block b = q >> 2, dword q & 3;
+        // 16-byte position (2b + {lo 0, hi 1}) ^ key, key = conflict-free swizzle of the fragment reads (see a_qfrag)
+        const int q = (lane & 7) ^ ((phx >> 1) & 7);
+        const int key = CT ? ((phy + 2 * (phx >> 2)) & 3) : ((phx >> 1) & 3);
+        const int qo = stage_off + A_BYTES + row * QROWB + ((((q >> 2) << 1) ^ key) << 4) + ((q & 3) << 2);
+        *(unsigned*)(smem + qo) = qlo;
+        *(unsigned*)(smem + (qo ^ 16)) = qhi;
+    };
+
+    // ---- weights: fp16 B fragments [cout/32][K/16][lane][8 halves]; MX fragments [cout/32][K/32][lane][16 B] + [..][8 B]; scales
+    // [cout/32][K/64][lane] dwords (byte 0: first 32-k block of the 64, byte 1: second)
+    const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
+    const unsigned lane_off = lane * 8;
+    f16x8 b[4][TN];
+    v4i bqa[2][TN]; v2i bqb[2][TN]; int bqs[TN];
+    auto load_b = [&](int kk, int tile_n, long koff) {      // koff: uniform offset (halves) of the step's first k-step in the fp16 array
+        const int cb0 = (tile_n * BN + wn * WTN) / 32;
+        const f16* wb = d.w_frag + (long)cb0 * nks * 512;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[kk][j] = *(const f16x8*)(wb + ((long)j * nks * 512 + koff + kk * 512) + lane_off);
+    };
+    auto load_bq = [&](int ms, int tile_n, long koff) {     // the MX fragments of 32-k block ms of the step (koff as in load_b)
+        const int cb0 = (tile_n * BN + wn * WTN) / 32;
+        const long mso = (koff >> 10) + ms;                  // MX step index: (koff / 512) / 2 + ms
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long fi = ((long)(cb0 + j) * nms + mso) * 64 + lane;
+            bqa[ms][j] = *(const v4i*)((const char*)d.wmx_a + fi * 16);
+            bqb[ms][j] = *(const v2i*)((const char*)d.wmx_b + fi * 8);
+        }
+    };
+    auto load_bs = [&](int tile_n, long koff) {
+        const int cb0 = (tile_n * BN + wn * WTN) / 32;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bqs[j] = *(const int*)((const char*)d.wmx_s + (((long)(cb0 + j) * (nms >> 1) + (koff >> 11)) * 64 + lane) * 4);
+    };
+
+    // A fragment addresses (see conv3x3_halo_rb.hip); fp4 plane: per-lane base per tap column (+ tap row for CT) with the swizzle key
+    const int fr = lane & 31, fh = lane >> 5;
+    int vt[3], vq[CT ? 4 : 3];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+        vt[tx] = ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * ROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 7)) << 4);
+    if (!CT) {
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+            vq[tx] = A_BYTES + ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * QROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 3)) << 4);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {       // key = (hy + 2 * (hx >> 2)) & 3, hy = wm*8 + (fr>>4) + 2i + ty: the 2i term is XORed in at the read
+            const int ty = t >> 1, tx = t & 1;
+            const int key = (((fr >> 4) + ty) + 2 * ((((fr & 15) + tx) >> 2) & 1)) & 3;
+            vq[t] = A_BYTES + ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * QROWB + ((fh ^ key) << 4);
+        }
+    }
+    auto a_frag = [&](int stage_off, int i, int ty, int tx, int kk) -> f16x8 {
+        return *(const f16x8*)(smem + ((vt[tx] + stage_off) ^ (kk << 5)) + (i * 2 * HW_ + ty * HW_ + tx) * ROWB);
+    };
+    auto a_qfrag = [&](int stage_off, int i, int ty, int tx, int ms) -> v4i {
+        const int base = CT ? vq[ty * 2 + tx] : vq[tx];
+        return *(const v4i*)(smem + ((base + stage_off) ^ (ms << 5) ^ (CT ? ((i & 1) << 5) : 0)) + (i * 2 * HW_ + ty * HW_ + tx) * QROWB);
+    };
+    // E8M0 scales of the activation side: lanes 0-31 carry a_lo (stored * 2^c_lo_exp), lanes 32-63 a_hi (stored * 2^-c_hi_exp)
+    const int a_scale = fh ? 127 + d.c_hi_exp : 127 - d.c_lo_exp;
+
+    const int nchunks = d.Cin >> 6;
+    // ---- prologue
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) load_b(kk, cur.tile_n, 0);
+    load_bq(0, cur.tile_n, 0); load_bq(1, cur.tile_n, 0); load_bs(cur.tile_n, 0);
+    if (NORM) {
+        stage_norm(cur, 0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
+    __syncthreads();
+    Pend pend = load_piece(cur, 0, 0);      // (placeholder value: overwritten before its first use)
+
+    f16x8 afr[2][TM];
+    v4i aq[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(0, i, 0, 0, 0);
+
+    int so = 0;                   // LDS offset of the halo stage of the current chunk (0 or STAGE_BYTES)
+    int slot = 0;                 // (scale, shift) slot of the current tile
+    for (;;) {
+        const TileAt nxt = tile_at(vb + gridDim.x);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const bool last = c + 1 == nchunks;
+            const bool to_next = last && nxt.valid;
+            const TileAt sta = to_next ? nxt : cur;
+            const int sc = last ? 0 : c + 1, sslot = to_next ? slot ^ 1 : slot;
+            if (NORM && nxt.valid && c == nchunks - 2) stage_norm(nxt, slot ^ 1);
+            // (CT) which input shifts t have a non-zero weight block for column block j of this wave (gdt_ctf_column: 64-column
+            // slices pair a cheap phase with an expensive one)
+            unsigned ct_mask[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int wq = (cur.tile_n * BN + wn * WTN + j * 32) >> 6;
+                const int pair = CT ? ((wq / (d.phase_cout >> 5)) & 1) : 0;
+                ct_mask[j] = pair == 0 ? ((j & 1) ? 0xFu : 0x1u) : ((j & 1) ? 0x5u : 0x3u);
+            }
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int ty = CT ? (t >> 1) : t / 3, tx = CT ? (t & 1) : t - ty * 3;
+                const int nty = CT ? ((t + 1) >> 1) : (t + 1) / 3, ntx = CT ? ((t + 1) & 1) : (t + 1) - nty * 3;
+                const long noff = (long)(t < NTAP - 1 ? (t + 1) * cin16 + c * 4 : sc * 4) * 512;
+                const int ntile_n = (t == NTAP - 1 && last) ? nxt.tile_n : cur.tile_n;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cu = kk & 1, nx = cu ^ 1;
+                    if (kk < 3) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, ty, tx, kk + 1);
+                    } else if (t < NTAP - 1) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, nty, ntx, 0);
+                    }
+                    if ((kk & 1) == 0) {          // the fp4 fragments of 32-k block kk / 2, consumed after the fp16 MFMAs of kk + 1
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) aq[i] = a_qfrag(so, i, ty, tx, kk >> 1);
+                    }
+                    if ((t * 4 + kk) % SPR == 0) {      // halo of the next chunk: one loader round in flight, written SPR substeps after its load
+                        constexpr int dummy = 0; (void)dummy;
+                        const int r = (t * 4 + kk) / SPR;
+                        if (r >= 1 && r - 1 < NR) store_piece(sslot, STAGE_BYTES - so, r - 1, pend);
+                        if (r < NR) pend = load_piece(sta, sc, r);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (!CT || ((ct_mask[j] >> t) & 1u)) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+                        }
+                    load_b(kk, ntile_n, noff);
+                    if (kk & 1) {                 // the correction product of the 32 k-values just done
+                        const int ms = kk >> 1;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            if (!CT || ((ct_mask[j] >> t) & 1u)) {
+                                const v8i wq = {bqa[ms][j][0], bqa[ms][j][1], bqa[ms][j][2], bqa[ms][j][3], bqb[ms][j][0], bqb[ms][j][1], 0, 0};
+                                const int ws = (int)__builtin_amdgcn_ubfe((unsigned)bqs[j], 8 * ms, 8);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) {
+                                    const v8i av = {aq[i][0], aq[i][1], aq[i][2], aq[i][3], 0, 0, 0, 0};
+                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq, av, acc[i][j], 2, 4, 0, ws, 0, a_scale);
+                                }
+                            }
+                        load_bq(ms, ntile_n, noff);
+                        if (ms == 1) load_bs(ntile_n, noff);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                so = STAGE_BYTES - so;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+            }
+        }
+
+        // ------------------------------------------------------------ tile end: all waves are done with the last halo stage and
+        // the next tile's first stage (written during the last chunk) is visible
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ------------------------------------------------------------ epilogue, straight from the accumulators (wave-private, no
+        // LDS): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3, the output channels 8g + 4fh .. +3 of
+        // column block j: one 16-byte fp32 store each.
+        if (!(d.dbg & 4)) {
+            float* __restrict__ outp = (float*)d.out;
+            const float* __restrict__ resp = (const float*)d.res;
+            int fr_e = fr, fh_e = fh;
+            asm volatile("" : "+v"(fr_e), "+v"(fh_e));
+            unsigned offs[TM]; unsigned okm = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = wm * WTM + i * 32 + fr_e;
+                const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
+                const bool ok = (y < d.H) & (x < d.W);
+                offs[i] = ok ? (unsigned)((cur.n * d.H + y) * d.W + x) : 0u;
+                okm |= (ok ? 1u : 0u) << i;
+            }
+            const bool relu_now = d.relu != 0;
+            float st[32];                                  // [which][g][c]: sum / sum of squares over this lane's pixels (CT: both phases)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int colb = cur.tile_n * BN + wn * WTN + j * 32 + 4 * fh_e;       // + 8g: this lane's channel quads
+                if (!CT || (j & 1) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) st[e] = 0.f;
+                }
+                float4 bv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[g] = d.bias ? *(const float4*)(d.bias + colb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bool ok = (okm >> i) & 1u;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& a = acc[i][j];
+                        float4 v = make_float4(a[4 * g] + bv[g].x, a[4 * g + 1] + bv[g].y, a[4 * g + 2] + bv[g].z, a[4 * g + 3] + bv[g].w);
+                        const bool okc = ok & (colb + 8 * g < d.Cout);
+                        if (CT) {
+                            // GEMM column -> (sub-pixel phase, output channel): quads never straddle a 32-column block
+                            int ph, co;
+                            gdt_ctf_column(colb + 8 * g, d.phase_cout, ph, co);
+                            const int m = wm * WTM + i * 32 + fr_e;
+                            const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
+                            if (okc) {
+                                if (d.stats) {
+                                    st[g * 4 + 0] += v.x; st[g * 4 + 1] += v.y; st[g * 4 + 2] += v.z; st[g * 4 + 3] += v.w;
+                                    st[16 + g * 4 + 0] += v.x * v.x; st[16 + g * 4 + 1] += v.y * v.y; st[16 + g * 4 + 2] += v.z * v.z; st[16 + g * 4 + 3] += v.w * v.w;
+                                }
+                                if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                                *(float4*)(outp + ((size_t)((cur.n * d.OH + 2 * y + (ph >> 1)) * d.OW + 2 * x + (ph & 1)) * d.phase_cout + co)) = v;
+                            }
+                            continue;
+                        }
+                        if (okc) {
+                            if (d.stats) {
+                                st[g * 4 + 0] += v.x; st[g * 4 + 1] += v.y; st[g * 4 + 2] += v.z; st[g * 4 + 3] += v.w;
+                                st[16 + g * 4 + 0] += v.x * v.x; st[16 + g * 4 + 1] += v.y * v.y; st[16 + g * 4 + 2] += v.z * v.z; st[16 + g * 4 + 3] += v.w * v.w;
+                            }
+                            const size_t o = (size_t)offs[i] * d.Cout + colb + 8 * g;
+                            if (resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                            if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            *(float4*)(outp + o) = v;
+                        }
+                    }
+                }
+                if (d.stats && (!CT || (j & 1) == 1)) {
+                    // halving butterfly over the 32 pixel lanes (fr): 32 values -> 1 per lane.  After the masks 16, 8, 4, 2, 1 lane
+                    // fr holds value index k = fr: which = fr >> 4, g = (fr >> 2) & 3, c = fr & 3.
+                    float v16[16], v8[8], v4[4], v2[2], v1;
+                    const bool b4 = (fr_e >> 4) & 1, b3 = (fr_e >> 3) & 1, b2 = (fr_e >> 2) & 1, b1 = (fr_e >> 1) & 1, b0 = fr_e & 1;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { const float snd = b4 ? st[k] : st[k + 16]; v16[k] = (b4 ? st[k + 16] : st[k]) + __shfl_xor(snd, 16); }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float snd = b3 ? v16[k] : v16[k + 8]; v8[k] = (b3 ? v16[k + 8] : v16[k]) + __shfl_xor(snd, 8); }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const float snd = b2 ? v8[k] : v8[k + 4]; v4[k] = (b2 ? v8[k + 4] : v8[k]) + __shfl_xor(snd, 4); }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) { const float snd = b1 ? v4[k] : v4[k + 2]; v2[k] = (b1 ? v4[k + 2] : v4[k]) + __shfl_xor(snd, 2); }
+                    { const float snd = b0 ? v2[0] : v2[1]; v1 = (b0 ? v2[1] : v2[0]) + __shfl_xor(snd, 1); }
+                    const int which = fr_e >> 4, g = (fr_e >> 2) & 3, cc = fr_e & 3;
+                    const int col = cur.tile_n * BN + wn * WTN + j * 32 + 8 * g + 4 * fh_e + cc;
+                    if (!CT) {
+                        if (col < d.Cout) d.stats[((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2 + which) * d.Cout + col] = v1;
+                    } else {
+                        // the wave's two column blocks are two sub-pixel phases of the same 32 output channels (summed in st above);
+                        // one record set per phase pair, the finalize kernel sums the two sets
+                        int ph, co;
+                        gdt_ctf_column(col, d.phase_cout, ph, co);
+                        const int pair = ((col >> 6) / (d.phase_cout >> 5)) & 1;
+                        d.stats[((long)(pair * (ntm * WGM) + cur.tile_m * WGM + wm) * 2 + which) * d.phase_cout + co] = v1;
+                    }
+                }
+            }
+        } else {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][15];
+            if (sacc == 12345.678f) ((float*)d.out)[0] = sacc;
+        }
+        if (!nxt.valid) break;
+        cur = nxt; vb += gridDim.x; slot ^= 1;
+        so = STAGE_BYTES - so;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+    }
+}
+
+template <int MODE, bool CT = false>
+int launch_c(const ConvLaunch& d, hipStream_t stream) {
+    constexpr int BN = 256, WGM = 2, WGN = 2;       // 4 waves of 128 pixels x 128 channels, one per SIMD (512 registers each)
+    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        GDT_CHECK_HIP(hipGetDevice(&dev));
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus / 8 * 8;
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    }
+    const int vblocks = gdt_grid_for_tiles(tiles, ntn);
+    const int grid = vblocks < cus ? vblocks : cus;
+    hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, CT>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, d, vblocks);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+}  // namespace
+
+// Eligible: 3x3 / stride 1 / pad 1 (zero or reflect), Cin % 64 == 0, 256-wide output tiles, the fp16 + MX fragment-ordered weights
+// present, whole patches when statistics are taken, enough patches to fill the chip; with a folded InstanceNorm 128 <= Cin <= 256.
+bool gdt_conv_halo_c_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_C"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 force
+    if (mode == 0 || !d.w_frag || !d.wmx_a || !d.wmx_b || !d.wmx_s) return false;
+    const bool shape = d.ntaps == 9 && d.TW == 3 && d.sy == 1 && d.sx == 1 && d.dy0 == -1 && d.dx0 == -1 && d.dys == 1 && d.dxs == 1 &&
+                       d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Cin % 64 == 0 && !d.out_f32 && d.Cout % 8 == 0 &&
+                       d.OH == d.H && d.OW == d.W && d.Kpad == 9 * d.Cin && d.CoutPad % 256 == 0 && !d.pool2 && !d.phase_cout;
+    if (!shape) return false;
+    if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
+    if ((d.in_res || d.in_out) && !d.in_norm) return false;
+    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;
+    if (mode == 2) return true;
+    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
+    const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
+    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();
+    return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
+}
+
+int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
+    static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
+    ConvLaunch d = d_in;
+    d.dbg = dbg;
+    if (!d.in_norm) return launch_c<0>(d, stream);
+    if (d.in_res) {
+        if (d.in_out) return launch_c<7>(d, stream);
+        return launch_c<3>(d, stream);
+    }
+    return d.in_out ? launch_c<5>(d, stream) : launch_c<1>(d, stream);
+}

@@ -31,6 +31,7 @@ struct PackedPhase {
     size_t w_off = 0;                 // byte offset in the device weight blob
     size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
     size_t w_frag_off = 0; bool has_frag = false;   // fp16 mode, 3x3 s1 p1: copy in MFMA B-fragment order (conv3x3_halo_rb.hip)
+    size_t wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
 };
@@ -115,7 +116,9 @@ struct gdt_net {
     size_t zeros_off = 0;
     bool finalized = false;
     int input_op = -1;
-    int precision = 0;                      // 0: fp16 activations, single MFMA pass; 1: "f16x3" (fp32 activations, split operands)
+    int precision = 0;                      // 0: fp16 activations, single MFMA pass; 1: "f16x3" (fp32 activations, split operands);
+                                            // 2: "f16c" (fp32 activations, fp16 product + block-scaled fp4 x fp6 correction product where a
+                                            //    compensated kernel exists, f16x3 kernels elsewhere)
     size_t esize() const { return precision ? sizeof(float) : sizeof(f16); }
     // optional per-op timing (bench.py roofline): HIP events recorded on the caller's stream around every op
     bool profiling = false;
@@ -258,7 +261,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     }
     for (int j = 0; j < nops && allow_norm_fusion; ++j) {
         const Op& oj = ops[j];
-        if (oj.kind != OP_INORM || net->precision) continue;          // f16x3: measured neutral
+        if (oj.kind != OP_INORM || net->precision == 1) continue;     // f16x3: measured neutral
         // plain norm(+ReLU): exactly one consumer.  norm + residual (ResnetBlock output): the tensor itself is still needed
         // later (as the next block's residual), so the consuming conv also writes it out -- every other consumer must come
         // after that conv in program order.
@@ -277,6 +280,16 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const Op& ok = ops[k];
         if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || (ok.cd.transposed && !plan.steps[k].ctf)) continue;
         if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
+        if (net->precision == 2) {                 // f16c: the compensated halo kernel folds norm (+ReLU, +residual, +write-back)
+            if (ok.rowsplit || !ok.phases[0].has_mx) continue;
+            ConvLaunch d{};
+            conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
+            d.w_frag = d.w = (const f16*)net; d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;         // non-null markers only
+            d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
+            d.in_norm = (const float*)net; d.in_res = oj.res >= 0 ? (const f16*)net : nullptr; d.in_out = wb ? (f16*)net : nullptr;
+            if (gdt_conv_halo_c_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
+            continue;
+        }
         ConvLaunch d{};
         if (plan.steps[k].ctf) {
             ctf_geometry(net, ok, N, T[ok.in], d);
@@ -435,6 +448,53 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
 }
 
 // ---- host-side weight packing ----------------------------------------------------------------------------------
+// e2m3 (OCP fp6: 1 sign, 2 exponent (bias 1), 3 mantissa bits; max 7.5, subnormal step 0.125), round to nearest even
+int quant_e2m3(float x) {
+    const int sign = std::signbit(x) ? 32 : 0;
+    float ax = std::fabs(x);
+    if (!(ax < 7.5f)) ax = 7.5f;
+    if (ax < 1.f) return sign | (int)std::nearbyint(ax * 8.f);          // 0 .. 8 (8 = 1.0: exponent field 1, mantissa 0)
+    int e = ax >= 4.f ? 2 : (ax >= 2.f ? 1 : 0);
+    int m = (int)std::nearbyint((std::ldexp(ax, -e) - 1.f) * 8.f);
+    if (m == 8) { m = 0; ++e; }
+    if (e > 2) { e = 2; m = 7; }
+    return sign | ((e + 1) << 3) | m;
+}
+
+// Block-scaled correction operands of a packed weight matrix wf [cout_pad][Kpad] (fp32, BatchNorm folded) in MFMA fragment order:
+// per (32-channel block cb, 32-k block ms, lane): lanes 0-31 hold fp16(w), lanes 32-63 hold w - fp16(w) of output channel cb*32 + (lane & 31),
+// each as 32 e2m3 values of  value * 2^-e  with the block's own E8M0 exponent byte 127 + e (largest magnitude of the block mapped into
+// (3.75, 7.5]).  Element i sits at bit 6i of the lane's 24 bytes; the first 16 go to `a`, the last 8 to `b`.
+void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<unsigned char>& a, std::vector<unsigned char>& b,
+             std::vector<unsigned>& sc) {
+    const int ncb = cout_pad / 32, nms = Kpad / 32;
+    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 8, 0); sc.assign((size_t)ncb * (nms / 2) * 64, 0);
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ms = 0; ms < nms; ++ms)
+            for (int ln = 0; ln < 64; ++ln) {
+                const float* src = wf.data() + (size_t)(cb * 32 + (ln & 31)) * Kpad + ms * 32;
+                float v[32], mx = 0.f;
+                for (int i = 0; i < 32; ++i) {
+                    const float hi = (float)(f16)src[i];
+                    v[i] = (ln >> 5) ? src[i] - hi : hi;
+                    mx = std::max(mx, std::fabs(v[i]));
+                }
+                int e = 0;
+                if (mx > 0.f) { e = (int)std::ceil(std::log2(mx / 7.5f)); if (std::ldexp(mx, -e) > 7.5f) ++e; }
+                e = std::min(std::max(e, -126), 127);
+                unsigned char bytes[24] = {0};
+                for (int i = 0; i < 32; ++i) {
+                    const unsigned code = (unsigned)quant_e2m3(std::ldexp(v[i], -e));
+                    const int bit = 6 * i;
+                    bytes[bit >> 3] |= (unsigned char)(code << (bit & 7));
+                    if ((bit & 7) > 2) bytes[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
+                }
+                const size_t fi = ((size_t)cb * nms + ms) * 64 + ln;
+                memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 8, bytes + 16, 8);
+                sc[((size_t)cb * (nms / 2) + (ms >> 1)) * 64 + ln] |= (unsigned)(127 + e) << (8 * (ms & 1));
+            }
+}
+
 void fold_bn(const gdt_conv_desc& cd, const float* bias, const float* g, const float* b, const float* m, const float* v,
              std::vector<float>& scale, std::vector<float>& shift, bool& has_shift) {
     scale.assign(cd.cout, 1.f); shift.assign(cd.cout, 0.f);
@@ -468,7 +528,7 @@ int gdt_net_create(gdt_net** net) {
 
 int gdt_net_set_precision(gdt_net* net, int mode) {
     GDT_REQUIRE(net && !net->finalized && net->ops.empty(), "precision must be chosen before the first op");
-    GDT_REQUIRE(mode == 0 || mode == 1, "precision mode: 0 = f16, 1 = f16x3");
+    GDT_REQUIRE(mode == 0 || mode == 1 || mode == 2, "precision mode: 0 = f16, 1 = f16x3, 2 = f16c");
     net->precision = mode;
     return GDT_OK;
 }
@@ -540,7 +600,9 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         const int K = ph.ntaps * cin_pad;
         ph.Kpad = (K + 63) / 64 * 64;
         std::vector<f16> pk((size_t)o.cout_pad * ph.Kpad, (f16)0.f), pl;
+        std::vector<float> wf;
         if (net->precision) pl.assign(pk.size(), (f16)0.f);
+        if (net->precision == 2) wf.assign(pk.size(), 0.f);
         for (int co = 0; co < cd.cout; ++co)
             for (int t = 0; t < ph.ntaps; ++t)
                 for (int c = 0; c < cd.cin; ++c) {
@@ -548,10 +610,19 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     const float w = wget(co, c, t) * scale[co];
                     pk[idx] = (f16)w;
                     if (net->precision) pl[idx] = (f16)((w - (float)pk[idx]) * 2048.f);
+                    if (net->precision == 2) wf[idx] = w;
                 }
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
         if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
-        if (!net->precision && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip
+        if (net->precision == 2 && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {   // conv3x3_halo_c.hip
+            std::vector<unsigned char> ma, mb; std::vector<unsigned> msc;
+            pack_mx(wf, o.cout_pad, ph.Kpad, ma, mb, msc);
+            ph.wmx_a_off = net->blob_append(ma.data(), ma.size());
+            ph.wmx_b_off = net->blob_append(mb.data(), mb.size());
+            ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
+            ph.has_mx = true;
+        }
+        if (net->precision != 1 && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip / conv3x3_halo_c.hip
             // fragment order: lane = fh * 32 + fr holds cout = cb * 32 + fr, k = ks * 16 + fh * 8 + e
             const int nks = ph.Kpad / 16;
             std::vector<f16> pf(pk.size());
@@ -870,7 +941,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
     auto& T = net->tensors;
     auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };      // element type is fp16 or fp32 (net->precision)
-    const int f32 = net->precision;
+    const int f32 = net->precision ? 1 : 0;      // activation element type handed to the helper kernels: fp32 in both split modes
     const f16* zeros = (const f16*)(net->dev_blob + net->zeros_off);
 
     if (net->profiling) {
@@ -925,6 +996,10 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.w = (const f16*)(net->dev_blob + ph.w_off);
                     d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
                     d.w_frag = ph.has_frag ? (const f16*)(net->dev_blob + ph.w_frag_off) : nullptr;
+                    if (ph.has_mx) {
+                        d.wmx_a = net->dev_blob + ph.wmx_a_off; d.wmx_b = net->dev_blob + ph.wmx_b_off; d.wmx_s = net->dev_blob + ph.wmx_s_off;
+                        d.c_lo_exp = 12; d.c_hi_exp = 0;
+                    }
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
@@ -939,7 +1014,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                             break;
                         }
                     }
-                    rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
+                    if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970256; rc = gdt_launch_conv_halo_c(d, st); }
+                    else rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;
                 }
