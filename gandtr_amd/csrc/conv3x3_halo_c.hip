@@ -25,6 +25,12 @@
 
 #include "gdt_common.h"
 
+// timing-only ablations (profiles/experiments): compile with -DGDT_C_ABL=<bits>; results are wrong by design
+//   1 no halo staging after the prologue   2 no MX MFMAs / MX weight loads   4 no fp16 weight re-loads   8 no fp16 MFMAs
+#ifndef GDT_C_ABL
+#define GDT_C_ABL 0
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;          // bytes per row of the fp16 plane (64 halves of K)
@@ -103,10 +109,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
         const int q = (lane & 7) ^ ((hx >> 1) & 7);
         Pend p;
-        p.goff = ((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + 3)) + (chunk * 8 + q) * 8;      // fp32 element offset (< 2^30, checked on the host)
+        p.goff = (((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + 3)) + (chunk * 8 + q) * 8) * 4u;      // byte offset (< 2^32, checked on the host)
         p.ok = (h < HROWS) & (inb | refl);
-        p.r0 = *(const float4*)(inf + p.goff); p.r1 = *(const float4*)(inf + p.goff + 4);
-        if (RES) { p.s0 = *(const float4*)(resf + p.goff); p.s1 = *(const float4*)(resf + p.goff + 4); }
+        p.r0 = *(const float4*)((const char*)inf + p.goff); p.r1 = *(const float4*)((const char*)inf + p.goff + 16);
+        if (RES) { p.s0 = *(const float4*)((const char*)resf + p.goff); p.s1 = *(const float4*)((const char*)resf + p.goff + 16); }
         return p;
     };
     float* nlds = (float*)(smem + 2 * STAGE_BYTES);
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         const int phy = (row * (CT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
         float a[8] = {p.r0.x, p.r0.y, p.r0.z, p.r0.w, p.r1.x, p.r1.y, p.r1.z, p.r1.w};
         if (NORM) {
-            const int cq = (p.goff >> 3) & ((1 << d.lc8) - 1);                     // chunk * 8 + q
+            const int cq = (p.goff >> 5) & ((1 << d.lc8) - 1);                     // chunk * 8 + q
             const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
             const float lo = d.in_relu ? 0.f : -3.0e38f;
 #pragma unroll
@@ -138,24 +144,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         // write-back of the transformed tensor (every piece stores the value of its clamped source pixel: identical bits from
         // neighbouring patches, no branch)
         if (WB) {
-            *(float4*)(wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
-            *(float4*)(wbf + p.goff + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            *(float4*)((char*)wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
+            *(float4*)((char*)wbf + p.goff + 16) = make_float4(a[4], a[5], a[6], a[7]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = p.ok ? a[e] : 0.f;
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)a[e];
-        unsigned qlo = 0, qhi = 0;
-#define GDT_Q4(k)                                                                                                     \
-        {                                                                                                             \
-            const float l0 = a[2 * k] - (float)o[2 * k], l1 = a[2 * k + 1] - (float)o[2 * k + 1];                    \
-            qlo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qlo, l0, l1, lo_scale, k);                                 \
-            f16x2 hp; hp[0] = o[2 * k]; hp[1] = o[2 * k + 1];                                                         \
-            qhi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(qhi, hp, hi_scale, k);                                     \
+        // split: o = fp16(a) (round to nearest even, two per instruction), a_lo = a - o in ONE v_fma_mix_f32 each (fp16 source read
+        // in place), both planes quantised to fp4 by the scaled converts (the convert divides by its scale operand)
+        unsigned ou[4], qlo = 0, qhi = 0;
+#define GDT_Q4(k)                                                                                                                    \
+        {                                                                                                                            \
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ou[k]) : "v"(a[2 * k]), "v"(a[2 * k + 1]));                                     \
+            float l0, l1;                                                                                                            \
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ou[k]), "v"(a[2 * k]));            \
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ou[k]), "v"(a[2 * k + 1]));        \
+            qlo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qlo, l0, l1, lo_scale, k);                                                \
+            qhi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(qhi, __builtin_bit_cast(f16x2, ou[k]), hi_scale, k);                       \
         }
         GDT_Q4(0) GDT_Q4(1) GDT_Q4(2) GDT_Q4(3)
 #undef GDT_Q4
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
+        const f16x8 o = __builtin_bit_cast(f16x8, ov);
         *(f16x8*)(smem + stage_off + row * ROWB + ((lane & 7) << 4)) = o;
         // fp4 plane: this thread holds source chunk q (channels 8q .. 8q+7): 32-channel block b = q >> 2, dword q & 3;
         // 16-byte position (2b + {lo 0, hi 1}) ^ key, key = conflict-free swizzle of the fragment reads (see a_qfrag)
@@ -166,32 +176,38 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         *(unsigned*)(smem + (qo ^ 16)) = qhi;
     };
 
-    // ---- weights: fp16 B fragments [cout/32][K/16][lane][8 halves]; MX fragments [cout/32][K/32][lane][16 B] + [..][8 B]; scales
-    // [cout/32][K/64][lane] dwords (byte 0: first 32-k block of the 64, byte 1: second)
+    // ---- weights, streamed L2 -> registers in MFMA fragment order.  Grouped layouts (net.hip pack_mx): the four 32-channel
+    // fragments a wave needs for one k-substep are contiguous, so one scalar base + 32-bit lane offset + an immediate (j * 1 KB)
+    // addresses each of them (the scalar-base form of global_load: no 64-bit vector address arithmetic):
+    //   w_cfrag [cout/128][K/16][4][64 lanes][16 B]      wmx_a [cout/128][K/32][4][64][16 B]      wmx_b [cout/128][K/32][4][64][12 B]
+    // (wmx_a + the first 8 bytes of wmx_b = the lane's 32 e2m3 values, the last 4 bytes of wmx_b = its E8M0 block scale).
+    // One wave per SIMD issues in order, so no load may wait on the MFMAs of its own substep: the fp16 fragments live in a ring of
+    // RING substep slices and substep u re-loads the slot that substep u - 1 has just finished with (slice u + RING - 1); the MX
+    // fragments of group g (32 k-values, MFMAs at the end of substep 2g + 1) are re-loaded with group g + 1 early in substep 2g + 2.
+    // Each substep issues its loads row by row between its MFMAs.
+    constexpr int RING = CT ? 4 : 3;
+    static_assert(SLOTS % RING == 0, "ring / buffer positions of a substep must not depend on the chunk");
+    static_assert(WTN == 128 && TN == 4 && TM == 4, "the weight streams are grouped per 128 output channels (one wave column)");
     const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
-    const unsigned lane_off = lane * 8;
-    f16x8 b[4][TN];
-    v4i bqa[2][TN]; v2i bqb[2][TN]; int bqs[TN];
-    auto load_b = [&](int kk, int tile_n, long koff) {      // koff: uniform offset (halves) of the step's first k-step in the fp16 array
-        const int cb0 = (tile_n * BN + wn * WTN) / 32;
-        const f16* wb = d.w_frag + (long)cb0 * nks * 512;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[kk][j] = *(const f16x8*)(wb + ((long)j * nks * 512 + koff + kk * 512) + lane_off);
+    typedef int v3i __attribute__((ext_vector_type(3)));
+    f16x8 b[RING][TN];
+    v8i bq[TN];             // registers 0-5: the lane's 32 e2m3 values, register 6: its block scale (loaded in place: dwordx4 + dwordx3)
+    auto lane_bytes = [&](int per_lane) -> unsigned {     // (opaque: keeps the zero-extension next to its load, which is what lets the
+        unsigned v = lane * per_lane;                      //  compiler pick the scalar-base addressing form)
+        asm volatile("" : "+v"(v));
+        return v;
     };
-    auto load_bq = [&](int ms, int tile_n, long koff) {     // the MX fragments of 32-k block ms of the step (koff as in load_b)
-        const int cb0 = (tile_n * BN + wn * WTN) / 32;
-        const long mso = (koff >> 10) + ms;                  // MX step index: (koff / 512) / 2 + ms
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const long fi = ((long)(cb0 + j) * nms + mso) * 64 + lane;
-            bqa[ms][j] = *(const v4i*)((const char*)d.wmx_a + fi * 16);
-            bqb[ms][j] = *(const v2i*)((const char*)d.wmx_b + fi * 8);
-        }
+    unsigned lo16 = lane_bytes(16), lo12 = lane_bytes(12);        // (refreshed at the top of every chunk body)
+    auto load_b = [&](int rs, int j, int tile_n, long ks) {       // ks: uniform k-substep index (16 k-values each)
+        const char* wb = (const char*)d.w_cfrag + ((long)(tile_n * (BN / WTN) + wn) * nks + ks) * 4096;
+        b[rs][j] = *(const f16x8*)(wb + lo16 + j * 1024);
     };
-    auto load_bs = [&](int tile_n, long koff) {
-        const int cb0 = (tile_n * BN + wn * WTN) / 32;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bqs[j] = *(const int*)((const char*)d.wmx_s + (((long)(cb0 + j) * (nms >> 1) + (koff >> 11)) * 64 + lane) * 4);
+    auto load_bq = [&](int j, int tile_n, long ks) {     // MX fragment j of the 32-k group starting at substep ks (even)
+        const long f0 = (long)(tile_n * (BN / WTN) + wn) * nms + (ks >> 1);
+        const v4i qa = *(const v4i*)((const char*)d.wmx_a + f0 * 4096 + lo16 + j * 1024);
+        const v3i qb = *(const v3i*)((const char*)d.wmx_b + f0 * 3072 + lo12 + j * 768);
+        bq[j] = __builtin_shufflevector(__builtin_shufflevector(qa, qa, 0, 1, 2, 3, -1, -1, -1, -1),
+                                             __builtin_shufflevector(qb, qb, 0, 1, 2, -1, -1, -1, -1, -1), 0, 1, 2, 3, 8, 9, 10, -1);
     };
 
     // A fragment addresses (see conv3x3_halo_rb.hip); fp4 plane: per-lane base per tap column (+ tap row for CT) with the swizzle key
@@ -212,12 +228,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             vq[t] = A_BYTES + ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * QROWB + ((fh ^ key) << 4);
         }
     }
-    auto a_frag = [&](int stage_off, int i, int ty, int tx, int kk) -> f16x8 {
-        return *(const f16x8*)(smem + ((vt[tx] + stage_off) ^ (kk << 5)) + (i * 2 * HW_ + ty * HW_ + tx) * ROWB);
+    // (the stage offset `so` is folded into vt / vq when the stage flips: STAGE_BYTES is a multiple of 128, the XORs below touch bits 5-6)
+    auto a_frag = [&](int i, int ty, int tx, int kk) -> f16x8 {
+        return *(const f16x8*)(smem + (vt[tx] ^ (kk << 5)) + (i * 2 * HW_ + ty * HW_ + tx) * ROWB);
     };
-    auto a_qfrag = [&](int stage_off, int i, int ty, int tx, int ms) -> v4i {
+    auto a_qfrag = [&](int i, int ty, int tx, int ms) -> v4i {
         const int base = CT ? vq[ty * 2 + tx] : vq[tx];
-        return *(const v4i*)(smem + ((base + stage_off) ^ (ms << 5) ^ (CT ? ((i & 1) << 5) : 0)) + (i * 2 * HW_ + ty * HW_ + tx) * QROWB);
+        return *(const v4i*)(smem + (base ^ (ms << 5) ^ (CT ? ((i & 1) << 5) : 0)) + (i * 2 * HW_ + ty * HW_ + tx) * QROWB);
+    };
+    auto flip_stage = [&](int delta) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vt[k] += delta;
+#pragma unroll
+        for (int k = 0; k < (CT ? 4 : 3); ++k) vq[k] += delta;
     };
     // E8M0 scales of the activation side: lanes 0-31 carry a_lo (stored * 2^c_lo_exp), lanes 32-63 a_hi (stored * 2^-c_hi_exp)
     const int a_scale = fh ? 127 + d.c_hi_exp : 127 - d.c_lo_exp;
@@ -225,8 +248,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     const int nchunks = d.Cin >> 6;
     // ---- prologue
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) load_b(kk, cur.tile_n, 0);
-    load_bq(0, cur.tile_n, 0); load_bq(1, cur.tile_n, 0); load_bs(cur.tile_n, 0);
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u) load_b(u, j, cur.tile_n, u);
+        load_bq(j, cur.tile_n, 0);
+    }
     if (NORM) {
         stage_norm(cur, 0);
         __syncthreads();
@@ -236,10 +262,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     __syncthreads();
     Pend pend = load_piece(cur, 0, 0);      // (placeholder value: overwritten before its first use)
 
-    f16x8 afr[2][TM];
-    v4i aq[TM];
+    f16x8 afr[TM];
+    v4i aq[TM];      // (TM == TN: row block j's fragments are fetched behind the MFMAs of column j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(0, i, 0, 0, 0);
+    for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
 
     int so = 0;                   // LDS offset of the halo stage of the current chunk (0 or STAGE_BYTES)
     int slot = 0;                 // (scale, shift) slot of the current tile
@@ -259,6 +285,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             const TileAt sta = to_next ? nxt : cur;
             const int sc = last ? 0 : c + 1, sslot = to_next ? slot ^ 1 : slot;
             if (NORM && nxt.valid && c == nchunks - 2) stage_norm(nxt, slot ^ 1);
+            lo16 = lane_bytes(16); lo12 = lane_bytes(12);
             // (CT) which input shifts t have a non-zero weight block for column block j of this wave (gdt_ctf_column: 64-column
             // slices pair a cheap phase with an expensive one)
             unsigned ct_mask[TN];
@@ -272,52 +299,72 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             for (int t = 0; t < NTAP; ++t) {
                 const int ty = CT ? (t >> 1) : t / 3, tx = CT ? (t & 1) : t - ty * 3;
                 const int nty = CT ? ((t + 1) >> 1) : (t + 1) / 3, ntx = CT ? ((t + 1) & 1) : (t + 1) - nty * 3;
-                const long noff = (long)(t < NTAP - 1 ? (t + 1) * cin16 + c * 4 : sc * 4) * 512;
-                const int ntile_n = (t == NTAP - 1 && last) ? nxt.tile_n : cur.tile_n;
+                // k-substep index (fp16 array) and tile of substep u of this chunk, u >= SLOTS: the first substeps of the chunk staged now
+                // (after the very last one this fetches the first slices again: unconditional loads keep the code straight-line)
+                auto ks_of = [&](int u) -> long { return u < SLOTS ? (long)((u >> 2) * cin16 + c * 4 + (u & 3)) : (long)(sc * 4 + (u - SLOTS)); };
+                auto tn_of = [&](int u) -> int { return (u >= SLOTS && last) ? nxt.tile_n : cur.tile_n; };
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int cu = kk & 1, nx = cu ^ 1;
-                    if (kk < 3) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, ty, tx, kk + 1);
-                    } else if (t < NTAP - 1) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, nty, ntx, 0);
-                    }
-                    if ((kk & 1) == 0) {          // the fp4 fragments of 32-k block kk / 2, consumed after the fp16 MFMAs of kk + 1
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) aq[i] = a_qfrag(so, i, ty, tx, kk >> 1);
-                    }
-                    if ((t * 4 + kk) % SPR == 0) {      // halo of the next chunk: one loader round in flight, written SPR substeps after its load
-                        constexpr int dummy = 0; (void)dummy;
-                        const int r = (t * 4 + kk) / SPR;
+                    const int u = t * 4 + kk, cu = kk & 1;
+                    if (!(GDT_C_ABL & 1) && u % SPR == 0) {      // halo of the next chunk: one loader round in flight, written SPR substeps after its load
+                        const int r = u / SPR;
                         if (r >= 1 && r - 1 < NR) store_piece(sslot, STAGE_BYTES - so, r - 1, pend);
                         if (r < NR) pend = load_piece(sta, sc, r);
                     }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (!CT || ((ct_mask[j] >> t) & 1u)) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
-                        }
-                    load_b(kk, ntile_n, noff);
-                    if (kk & 1) {                 // the correction product of the 32 k-values just done
-                        const int ms = kk >> 1;
+                    for (int i = 0; i < TM; ++i) {
+                        // row block i: its MFMAs over the wave's columns share the activation fragment, which is then re-loaded IN PLACE
+                        // for the next substep (single-buffered: 16 registers instead of 32)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            if (!CT || ((ct_mask[j] >> t) & 1u)) {
-                                const v8i wq = {bqa[ms][j][0], bqa[ms][j][1], bqa[ms][j][2], bqa[ms][j][3], bqb[ms][j][0], bqb[ms][j][1], 0, 0};
-                                const int ws = (int)__builtin_amdgcn_ubfe((unsigned)bqs[j], 8 * ms, 8);
-#pragma unroll
-                                for (int i = 0; i < TM; ++i) {
-                                    const v8i av = {aq[i][0], aq[i][1], aq[i][2], aq[i][3], 0, 0, 0, 0};
-                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq, av, acc[i][j], 2, 4, 0, ws, 0, a_scale);
-                                }
-                            }
-                        load_bq(ms, ntile_n, noff);
-                        if (ms == 1) load_bs(ntile_n, noff);
+                            if (!(GDT_C_ABL & 8) && (!CT || ((ct_mask[j] >> t) & 1u)))
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+                        // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
+                        // substeps) the fp4 fragment and column i of the MX weights two groups ahead
+                        if (!(GDT_C_ABL & 4)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
+                        if (kk < 3) afr[i] = a_frag(i, ty, tx, kk + 1);
+                        else if (t < NTAP - 1) afr[i] = a_frag(i, nty, ntx, 0);
+                        if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all four columns are re-loaded
+                            aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first two rows: >= 24 MFMAs before their first use)
+                            if (!(GDT_C_ABL & 2) && i < 2) { load_bq(2 * i, tn_of(u), ks_of(u)); load_bq(2 * i + 1, tn_of(u), ks_of(u)); }
+                        }
                     }
+                    if (!(GDT_C_ABL & 2) && cu == 1) {          // the correction product of the 32 k-values just done
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                if (!CT || ((ct_mask[j] >> t) & 1u)) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
+                                }
+                        }
+                    }
+                    // in-order issue: lay the substep out as MFMA, a few VALU (the halo staging), MFMA, ... with the memory operations
+                    // of a column behind its MFMAs
+#ifndef GDT_C_NOSCHED
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                        }
+                        if (cu == 0 && j < 2) { __builtin_amdgcn_sched_group_barrier(0x020, 5, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }   // global loads, LDS reads
+                        else if (cu == 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                        else { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // LDS write
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);      // global store
+                    }
+                    if (cu == 1) {
+#pragma unroll
+                        for (int m = 0; m < TM * TN; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        }
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -325,9 +372,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                flip_stage(STAGE_BYTES - 2 * so);
                 so = STAGE_BYTES - so;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+                for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
             }
         }
 
@@ -440,9 +488,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         }
         if (!nxt.valid) break;
         cur = nxt; vb += gridDim.x; slot ^= 1;
+        flip_stage(STAGE_BYTES - 2 * so);
         so = STAGE_BYTES - so;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+        for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
     }
 }
 
@@ -472,7 +521,7 @@ int launch_c(const ConvLaunch& d, hipStream_t stream) {
 // present, whole patches when statistics are taken, enough patches to fill the chip; with a folded InstanceNorm 128 <= Cin <= 256.
 bool gdt_conv_halo_c_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_C"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 force
-    if (mode == 0 || !d.w_frag || !d.wmx_a || !d.wmx_b || !d.wmx_s) return false;
+    if (mode == 0 || !d.w_cfrag || !d.wmx_a || !d.wmx_b || !d.wmx_s) return false;
     const bool shape = d.ntaps == 9 && d.TW == 3 && d.sy == 1 && d.sx == 1 && d.dy0 == -1 && d.dx0 == -1 && d.dys == 1 && d.dxs == 1 &&
                        d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Cin % 64 == 0 && !d.out_f32 && d.Cout % 8 == 0 &&
                        d.OH == d.H && d.OW == d.W && d.Kpad == 9 * d.Cin && d.CoutPad % 256 == 0 && !d.pool2 && !d.phase_cout;
@@ -480,7 +529,7 @@ bool gdt_conv_halo_c_eligible(const ConvLaunch& d) {
     if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
     if ((d.in_res || d.in_out) && !d.in_norm) return false;
     if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
-    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 30) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;
     if (mode == 2) return true;
     const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
     const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
@@ -498,4 +547,29 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
         return launch_c<3>(d, stream);
     }
     return d.in_out ? launch_c<5>(d, stream) : launch_c<1>(d, stream);
+}
+
+// Transposed form (CT): ConvTranspose2d(k3,s2,p1,op1) as one launch (phase_cout > 0, weights of Op::ctf packed by pack_mx), 64 or 128
+// channels per phase, enough patches to fill the chip, at most 15 % padding waste; with statistics whole 16x16 patches; a folded
+// InstanceNorm needs 128 <= Cin <= 256 (table slots, staged one chunk ahead).
+bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_C"); return e ? atoi(e) : 1; }();   // 0 off
+    if (mode == 0 || !d.phase_cout || !d.w_cfrag || !d.wmx_a || !d.wmx_b || !d.out || d.out_f32 || d.res || d.in_out) return false;
+    if ((d.phase_cout != 64 && d.phase_cout != 128) || d.Cout != 4 * d.phase_cout || d.CoutPad != d.Cout || d.Cin % 64 != 0) return false;
+    if (d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.pad_reflect) return false;
+    if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
+    if (d.in_res && !d.in_norm) return false;
+    if (d.stats && ((d.H & 15) || (d.W & 15))) return false;
+    if ((long)d.N * d.H * d.W * d.Cin >= (1L << 30) || (long)d.N * d.OH * d.OW * d.phase_cout >= (1L << 32)) return false;
+    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
+    const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
+    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();
+    return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
+}
+
+int gdt_launch_conv_halo_c_ct(const ConvLaunch& d_in, hipStream_t stream) {
+    ConvLaunch d = d_in;
+    d.dbg = 0;
+    if (!d.in_norm) return launch_c<0, true>(d, stream);
+    return d.in_res ? launch_c<3, true>(d, stream) : launch_c<1, true>(d, stream);
 }

@@ -71,9 +71,10 @@ struct ConvLaunch {
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
     int pool2;                    // 1: MaxPool2d(2, 2) fused into the epilogue of the patch kernels; `out` is the pooled [N][H/2][W/2][Cout] tensor
     // "f16c" precision mode (conv3x3_halo_c.hip): block-scaled correction operands of the weights in MFMA fragment order --
-    // wmx_a [CoutPad/32][Kpad/32][64 lanes][16 B] and wmx_b [..][8 B]: 32 e2m3 values per lane (lanes 0-31: fp16(w) of output channel
-    // lane, lanes 32-63: w - fp16(w), same 32 k-values); wmx_s [CoutPad/32][Kpad/64][64] dwords: E8M0 block scales (byte 0 / 1 = first /
+    // wmx_a [CoutPad/128][Kpad/32][4][64 lanes][16 B] and wmx_b [..][12 B]: 32 e2m3 values per lane (24 bytes) + its E8M0 block scale (1 dword) (lanes 0-31: fp16(w) of output channel
+    // lane, lanes 32-63: w - fp16(w), same 32 k-values); wmx_s [CoutPad/128][Kpad/64][4][64] dwords: E8M0 block scales (byte 0 / 1 = first /
     // second 32-k block).  Activation side: a_lo is stored as fp4(a_lo * 2^c_lo_exp), a_hi as fp4(a_hi * 2^-c_hi_exp).
+    const void* w_cfrag;          // fp16 weights grouped per 128 output channels: [CoutPad/128][Kpad/16][4][64 lanes][8 halves] (wmx_* grouped alike)
     const void* wmx_a; const void* wmx_b; const void* wmx_s;
     int c_lo_exp, c_hi_exp;
     int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
@@ -127,4 +128,6 @@ bool gdt_conv_halo_x3_eligible(const ConvLaunch& d);       // conv3x3_halo_x3.hi
 int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_eligible(const ConvLaunch& d);         // conv3x3_halo_c.hip (f16c mode, variant 970256)
 int gdt_launch_conv_halo_c(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
+int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

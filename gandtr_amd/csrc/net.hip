@@ -31,7 +31,7 @@ struct PackedPhase {
     size_t w_off = 0;                 // byte offset in the device weight blob
     size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
     size_t w_frag_off = 0; bool has_frag = false;   // fp16 mode, 3x3 s1 p1: copy in MFMA B-fragment order (conv3x3_halo_rb.hip)
-    size_t wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
+    size_t wc_off = 0, wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
 };
@@ -233,6 +233,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         ctf_geometry(net, o, N, T[o.in], d);
         d.w_frag = (const f16*)net; d.out = (f16*)net;                                 // non-null markers only
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
+        if (net->precision == 2) {                 // f16c: the compensated LDS-resident form whenever eligible
+            d.w_frag = nullptr; d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net;
+            if (o.ctf.has_mx && gdt_conv_halo_c_ct_eligible(d)) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
+            continue;
+        }
         // GDT_CONV_CTF: 0 never, 1 (default) the LDS-resident kernel whenever eligible and the generic persistent GEMM only where
         // it lets the producer's InstanceNorm be folded in, 2 whenever eligible
         static const int ctf_mode = [] { const char* e = getenv("GDT_CONV_CTF"); return e ? atoi(e) : 1; }();
@@ -280,11 +285,20 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const Op& ok = ops[k];
         if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || (ok.cd.transposed && !plan.steps[k].ctf)) continue;
         if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
+        if (plan.steps[k].ctf && net->precision == 2) {
+            ConvLaunch d{};
+            ctf_geometry(net, ok, N, T[ok.in], d);
+            d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;
+            d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
+            d.in_norm = (const float*)net; d.in_res = oj.res >= 0 ? (const f16*)net : nullptr;
+            if (consumers[oj.out] == 1 && gdt_conv_halo_c_ct_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            continue;
+        }
         if (net->precision == 2) {                 // f16c: the compensated halo kernel folds norm (+ReLU, +residual, +write-back)
             if (ok.rowsplit || !ok.phases[0].has_mx) continue;
             ConvLaunch d{};
             conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
-            d.w_frag = d.w = (const f16*)net; d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;         // non-null markers only
+            d.w = (const f16*)net; d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;         // non-null markers only
             d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
             d.in_norm = (const float*)net; d.in_res = oj.res >= 0 ? (const f16*)net : nullptr; d.in_out = wb ? (f16*)net : nullptr;
             if (gdt_conv_halo_c_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
@@ -465,10 +479,19 @@ int quant_e2m3(float x) {
 // per (32-channel block cb, 32-k block ms, lane): lanes 0-31 hold fp16(w), lanes 32-63 hold w - fp16(w) of output channel cb*32 + (lane & 31),
 // each as 32 e2m3 values of  value * 2^-e  with the block's own E8M0 exponent byte 127 + e (largest magnitude of the block mapped into
 // (3.75, 7.5]).  Element i sits at bit 6i of the lane's 24 bytes; the first 16 go to `a`, the last 8 to `b`.
+// Layouts are grouped per 128 output channels (see ConvLaunch::w_cfrag): index = ((group * steps + step) * 4 + block in group) * 64 + lane.
 void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<unsigned char>& a, std::vector<unsigned char>& b,
-             std::vector<unsigned>& sc) {
-    const int ncb = cout_pad / 32, nms = Kpad / 32;
-    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 8, 0); sc.assign((size_t)ncb * (nms / 2) * 64, 0);
+             std::vector<unsigned>& sc, std::vector<f16>& wc) {
+    const int ncb = cout_pad / 32, nms = Kpad / 32, nks = Kpad / 16;
+    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 12, 0); sc.clear();
+    wc.assign((size_t)cout_pad * Kpad, (f16)0.f);
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int ln = 0; ln < 64; ++ln) {
+                const float* src = wf.data() + (size_t)(cb * 32 + (ln & 31)) * Kpad + ks * 16 + (ln >> 5) * 8;
+                f16* dst = wc.data() + ((((size_t)(cb >> 2) * nks + ks) * 4 + (cb & 3)) * 64 + ln) * 8;
+                for (int e = 0; e < 8; ++e) dst[e] = (f16)src[e];
+            }
     for (int cb = 0; cb < ncb; ++cb)
         for (int ms = 0; ms < nms; ++ms)
             for (int ln = 0; ln < 64; ++ln) {
@@ -489,9 +512,9 @@ void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<u
                     bytes[bit >> 3] |= (unsigned char)(code << (bit & 7));
                     if ((bit & 7) > 2) bytes[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
                 }
-                const size_t fi = ((size_t)cb * nms + ms) * 64 + ln;
-                memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 8, bytes + 16, 8);
-                sc[((size_t)cb * (nms / 2) + (ms >> 1)) * 64 + ln] |= (unsigned)(127 + e) << (8 * (ms & 1));
+                const size_t fi = (((size_t)(cb >> 2) * nms + ms) * 4 + (cb & 3)) * 64 + ln;
+                const unsigned scale = (unsigned)(127 + e);           // E8M0 block scale rides behind the lane's data
+                memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 12, bytes + 16, 8); memcpy(b.data() + fi * 12 + 8, &scale, 4);
             }
 }
 
@@ -614,15 +637,16 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 }
         ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
         if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
-        if (net->precision == 2 && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {   // conv3x3_halo_c.hip
-            std::vector<unsigned char> ma, mb; std::vector<unsigned> msc;
-            pack_mx(wf, o.cout_pad, ph.Kpad, ma, mb, msc);
+        if (net->precision == 2 && cin_pad % 64 == 0 && o.cout_pad % 128 == 0) {   // conv3x3_halo_c.hip
+            std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
+            pack_mx(wf, o.cout_pad, ph.Kpad, ma, mb, msc, wc);
+            ph.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
             ph.wmx_a_off = net->blob_append(ma.data(), ma.size());
             ph.wmx_b_off = net->blob_append(mb.data(), mb.size());
-            ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
+            ph.wmx_s_off = ph.wmx_b_off;
             ph.has_mx = true;
         }
-        if (net->precision != 1 && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip / conv3x3_halo_c.hip
+        if (!net->precision && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip
             // fragment order: lane = fh * 32 + fr holds cout = cb * 32 + fr, k = ks * 16 + fh * 8 + e
             const int nks = ph.Kpad / 16;
             std::vector<f16> pf(pk.size());
@@ -706,13 +730,15 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 });
                 o.phases.push_back(ph);
             }
-        if (!net->precision && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && cd.cout >= 64 && residual_tensor < 0) {
+        if (net->precision != 1 && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && cd.cout >= 64 && residual_tensor < 0) {
             // fused form: GEMM column -> (phase py * 2 + px, co) by gdt_ctf_column(), k = (dy * 2 + dx) * cin + c over the 2x2 input
             // shifts; a (shift, phase) pair that does not occur is a zero block (16 blocks, 9 non-zero) the kernel skips
             PackedPhase& cf = o.ctf;
             cf.ntaps = 4; cf.TW = 2; cf.dy0 = 0; cf.dys = 1; cf.dx0 = 0; cf.dxs = 1; cf.Kpad = 4 * cin_pad;
             const int ncol = 4 * cd.cout, nks = cf.Kpad / 16;
             std::vector<f16> pk((size_t)ncol * cf.Kpad, (f16)0.f);
+            std::vector<float> wf;
+            if (net->precision == 2) wf.assign(pk.size(), 0.f);
             for (int col = 0; col < ncol; ++col) {
                 int phase, co;
                 gdt_ctf_column(col, cd.cout, phase, co);
@@ -721,20 +747,30 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     for (int dx = 0; dx < 2; ++dx) {
                         const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
                         if (ky < 0 || kx < 0) continue;
-                        for (int c = 0; c < cd.cin; ++c)
-                            pk[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] =
-                                (f16)(weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co]);
+                        for (int c = 0; c < cd.cin; ++c) {
+                            const float w = weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co];
+                            pk[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] = (f16)w;
+                            if (net->precision == 2) wf[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] = w;
+                        }
                     }
             }
-            std::vector<f16> pf(pk.size());
-            for (int cb = 0; cb < ncol / 32; ++cb)
+            if (net->precision == 2) {          // conv3x3_halo_c.hip, transposed form
+                std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
+                pack_mx(wf, ncol, cf.Kpad, ma, mb, msc, wc);
+                cf.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
+                cf.wmx_a_off = net->blob_append(ma.data(), ma.size());
+                cf.wmx_b_off = net->blob_append(mb.data(), mb.size());
+                cf.wmx_s_off = cf.wmx_b_off;
+                cf.has_mx = true;
+            }
+            std::vector<f16> pf(net->precision ? 0 : pk.size());
+            for (int cb = 0; cb < (net->precision ? 0 : ncol / 32); ++cb)
                 for (int ks = 0; ks < nks; ++ks)
                     for (int ln = 0; ln < 64; ++ln) {
                         const f16* src = pk.data() + (size_t)(cb * 32 + (ln & 31)) * cf.Kpad + ks * 16 + (ln >> 5) * 8;
                         std::copy(src, src + 8, pf.data() + (((size_t)cb * nks + ks) * 64 + ln) * 8);
                     }
-            cf.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
-            cf.has_frag = true;
+            if (!net->precision) { cf.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16)); cf.has_frag = true; }
             if (has_shift) {
                 std::vector<float> b4(ncol);
                 for (int i = 0; i < ncol; ++i) { int ph, co; gdt_ctf_column(i, cd.cout, ph, co); b4[i] = shift[co]; }
@@ -977,9 +1013,15 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     ctf_geometry(net, o, n, ti, d);
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.ctf_bias_off) : nullptr;
                     d.out = tptr(o.out); d.out_f32 = nullptr;
-                    d.w = nullptr; d.w_lo = nullptr; d.w_frag = (const f16*)(net->dev_blob + o.ctf.w_frag_off);
+                    d.w = nullptr; d.w_lo = nullptr; d.w_frag = o.ctf.has_frag ? (const f16*)(net->dev_blob + o.ctf.w_frag_off) : nullptr;
                     d.stats_tile_base = 0;
                     int variant = 960256;
+                    if (net->precision == 2) {
+                        d.w_cfrag = net->dev_blob + o.ctf.wc_off; d.wmx_a = net->dev_blob + o.ctf.wmx_a_off; d.wmx_b = d.wmx_s = net->dev_blob + o.ctf.wmx_b_off;
+                        d.c_lo_exp = 12; d.c_hi_exp = 0;
+                        variant = 980256;
+                        rc = gdt_launch_conv_halo_c_ct(d, st);
+                    } else
                     rc = gdt_conv_halo_ct_eligible(d) ? gdt_launch_conv_halo_ct(d, st) : gdt_launch_conv_igemm_rb(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     break;
@@ -997,7 +1039,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.w_lo = f32 ? (const f16*)(net->dev_blob + ph.w_lo_off) : nullptr;
                     d.w_frag = ph.has_frag ? (const f16*)(net->dev_blob + ph.w_frag_off) : nullptr;
                     if (ph.has_mx) {
-                        d.wmx_a = net->dev_blob + ph.wmx_a_off; d.wmx_b = net->dev_blob + ph.wmx_b_off; d.wmx_s = net->dev_blob + ph.wmx_s_off;
+                        d.w_cfrag = net->dev_blob + ph.wc_off; d.wmx_a = net->dev_blob + ph.wmx_a_off; d.wmx_b = net->dev_blob + ph.wmx_b_off; d.wmx_s = net->dev_blob + ph.wmx_s_off;
                         d.c_lo_exp = 12; d.c_hi_exp = 0;
                     }
                     d.stats_tile_base = phase_idx * (d.M / 128);

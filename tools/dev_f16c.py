@@ -96,3 +96,67 @@ if "time" in what:
             if ms > 0.02:
                 print("    %-8s variant %-7d x%-3d %.3f ms  %s" % (k[0], k[1], cnt, ms, ("%.0f TFLOP/s" % (fl / ms / 1e9)) if fl else ""))
         net.set_profiling(False)
+
+if "bench" in what:
+    # sustained timing of the resblock conv (256 -> 256, 64 x 64, batch 64) repeated 8 times on the same input
+    prec = os.environ.get("PREC", "f16c")
+    net = HipNet(dev, prec)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "w0", (256, 3, 1, 1), 0.5))
+    outs = [net.conv(a, synth._normal(0, "w", (256, 256, 3, 3), 0.02), pad=1, reflect=True) for _ in range(8)]
+    net.gem_l2n(outs[-1], 3.0)
+    net.finalize()
+    x = synth.synth_input(1, (64, 3, 64, 64)).to(dev)
+    for _ in range(3):
+        net.forward(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(30):
+        net.forward(x)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 30
+    net.set_profiling(True); net.forward(x); p = net.profile()
+    convs = [(var, ms, fl) for kind, var, ms, fl in p if kind == 1][-8:]
+    other = sum(ms for kind, var, ms, fl in p) - sum(c[1] for c in convs)
+    print("%s lib %s: sustained %.3f ms per forward; per conv (sustained - other) %.3f ms, profiled %.3f ms, variant %d, %.0f TFLOP/s"
+          % (prec, os.path.basename(os.environ.get("GANDTR_HIP_LIB", "default")), dt * 1e3, (dt * 1e3 - other) / 8, sum(c[1] for c in convs) / 8, convs[-1][0],
+             convs[-1][2] / ((dt * 1e3 - other) / 8) / 1e9), flush=True)
+
+if "ct" in what:
+    def single_ct(precision, cin, cout, n=8, h=64, w=64, norm=False, res=False, seed=0):
+        g = lambda name, shape, std=1.0: synth._normal(seed, name, shape, std)
+        net = HipNet(dev, precision)
+        t = net.input(3)
+        t0 = net.conv(t, g("w0", (cin, 3, 1, 1), 0.7))
+        t = t0
+        if norm:
+            r = net.conv(net.input_tensor if False else t0, g("w1", (cin, cin, 1, 1), 0.1)) if res else -1
+            t = net.instance_norm(t0, relu=not res, residual=r)
+        wt = g("w", (cin, cout, 3, 3), 0.05)
+        bias = g("b", (cout,), 0.2)
+        out = net.conv(t, wt, bias, stride=2, pad=1, transposed=True)
+        o2 = net.instance_norm(out, relu=True)          # makes the conv take statistics
+        tap_out = net.output_nchw(out)
+        tap_n = net.output_nchw(o2)
+        net.finalize()
+        x = synth.synth_input(seed + 1, (n, 3, h, w))
+        outs = net.forward(x.to(dev))
+        # reference from the same (exact) 1x1 lifts, computed in fp64 on the host
+        xd = x.double()
+        a0 = F.conv2d(xd, g("w0", (cin, 3, 1, 1), 0.7).double())
+        a = a0
+        if norm:
+            a = F.instance_norm(a0, eps=1e-5)
+            if res:
+                a = a + F.conv2d(a0, g("w1", (cin, cin, 1, 1), 0.1).double())
+            else:
+                a = F.relu(a)
+        ref = F.conv_transpose2d(a, wt.double(), bias.double(), stride=2, padding=1, output_padding=1)
+        refn = F.relu(F.instance_norm(ref, eps=1e-5))
+        return rel(outs[tap_out].double().cpu(), ref), rel(outs[tap_n].double().cpu(), refn)
+    for prec in ("f16x3", "f16c"):
+        for (cin, cout) in ((256, 128), (128, 64)):
+            for norm, res in ((False, False), (True, False), (True, True)):
+                if res and cin != 256:
+                    continue
+                print("convT %d->%d %-6s norm %d res %d: rel err (conv, IN+ReLU of it) %s" % (cin, cout, prec, norm, res, "%.3e %.3e" % single_ct(prec, cin, cout, norm=norm, res=res)), flush=True)
