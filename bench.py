@@ -115,6 +115,10 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 980000:
+        return "conv3x3_halo_c_kernel<256>[transposed]"
+    if variant >= 970000:
+        return "conv3x3_halo_c_kernel<%d>" % (variant - 970000)
     if variant >= 960000:
         return "conv3x3_halo_rb_kernel<256>[transposed]"
     if variant >= 950000:
@@ -228,12 +232,69 @@ def cpu_baseline_r101(seconds=10.0):
             "sample": "%d images (1x3x1024x1024) in %.1f s, torch CPU fp32 oracle, %d threads" % (n, dt, cores)}
 
 
-def main():
-    # RCCL prints a version banner to stdout on first use; the driver expects exactly one JSON line there, so everything
-    # but the final line goes to stderr.
+def self_launch(argv, gpus, dry_run):
+    """`python bench.py --gpus N` without a launcher: the parent (which never touches the GPU) starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, relays rank 0's single JSON line and
+    the exit code.  No exec of a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["GANDTR_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, check=False)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank launch failed (rc %d)\n" % (gpus, proc.returncode))
+        return proc.returncode or 1
+    sys.stdout.write(lines[-1] + "\n")
     sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+    return 0
+
+
+def dry_run(a, real_stdout):
+    """Launcher / protocol rehearsal without a GPU (tests/test_bench_launcher.py): gloo backend, CPU tensors, a stand-in step, the
+    same barrier + max-over-ranks timing and the same all-gather of a descriptor block.  The line is marked "dry_run": true."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("gloo")
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+    x = torch.randn(64, 64)
+    for _ in range(a.warmup):
+        x @ x
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x @ x
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        d = sharding.all_gather_descriptors(torch.full((2, 8), float(rank)), 2 * world)
+        assert d.shape == (8, 2 * world) and float(d[0, -1]) == world - 1
+    if rank == 0:
+        line = {"metric": "images/sec generator@256^2 + descriptors/sec GeM-R101@1024^2, 1/2/4/8 MI355X", "value": 0.0, "unit": "images/s",
+                "n_gpus": world, "rccl_ranks": dist.get_world_size() if distributed else 1, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(dt / max(1, a.steps) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "none", "data": "synthetic", "dry_run": True, "config": {"workload": "launcher rehearsal on CPU (gloo), no GPU work"}}
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -241,23 +302,42 @@ def main():
     ap.add_argument("--gen-batch", type=int, default=64)
     ap.add_argument("--r101-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact", action="store_true", help="skip the f16x3 (1e-3-exact) generator measurement")
+    ap.add_argument("--no-fast", action="store_true", help="skip the single-pass fp16 (fast_mode) generator measurement")
+    ap.add_argument("--no-exact", action="store_true", help="skip the f16x3 (three-pass split) generator measurement")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / protocol rehearsal on CPU with gloo (no GPU work)")
     a = ap.parse_args()
+
+    # ---- self-launch: N > 1 asked for, but no launcher environment -> start the ranks as children, before any GPU call
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], a.gpus, a.dry_run))
+
+    # RCCL prints a version banner to stdout on first use; the driver expects exactly one JSON line there, so everything
+    # but the final line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if a.dry_run:
+        return dry_run(a, real_stdout)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("GANDTR_BENCH_FORCE_DIST") == "1"    # the latter: exercise the RCCL path on one GPU
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launcher mismatch)\n" % (a.gpus, world))
+        sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if distributed:
         dist.init_process_group("nccl", device_id=dev)
+    rccl_ranks = dist.get_world_size() if distributed else 1
 
-    # ---------------------------------------------------------------- primary: generator images/s
+    # ---------------------------------------------------------------- primary: generator images/s in the tolerance-compliant mode
+    # "f16c": fp32 activations, fp16 MFMA product + block-scaled fp4 x fp6 correction MFMA (conv3x3_halo_c.hip); every generator
+    # tap within 1e-3 of the fp32 oracle (tests/test_hip_models.py, tests/test_hip_fullsize_properties.py)
     gsd = synth.generator_state(0, "instance", gain=0.02)
-    gen = engine.build_generator(gsd, dev)
+    gen = engine.build_generator(gsd, dev, precision="f16c")
     xg = synth.synth_input(1000 + rank, (a.gen_batch, 3, 256, 256), 1.0).to(dev)
     sampler = ClockSampler(dev) if rank == 0 else None
     if sampler is not None:
@@ -266,7 +346,7 @@ def main():
     else:
         dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
     mfma_only = None
-    if rank == 0:          # sustained rate of the matrix pipe alone on this very device, measured right after the timed region
+    if rank == 0:          # sustained rate of the fp16 matrix pipe alone on this very device, measured right after the timed region
         try:
             import ctypes
             from gandtr_amd import _hip
@@ -277,16 +357,15 @@ def main():
             print("mfma-only measurement failed: %r" % (exc,), file=sys.stderr)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
-    roof = conv_roofline(gen, xg, traffic_key="r01_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    roof = conv_roofline(gen, xg, traffic_key="r02_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    if roof is not None:
+        # the kernel issues 1.5 MFMA-slots per algorithmic fp16 one (1 fp16 + 1/2 block-scaled): its matrix pipe work is 1.5 x `achieved`
+        roof["mfma_work_factor"] = 1.5
     if roof is not None and mfma_only:
-        # context for `frac`: what the matrix pipe alone sustains on this device (power-limited clock), and the dominant
-        # kernel against that
         roof["mfma_only_sustained"] = mfma_only
         roof["frac_of_mfma_only"] = round(roof["achieved"] / mfma_only, 4)
     clocks = sampler.summary() if sampler is not None else None
     if roof is not None and clocks:
-        # the engine clock the timed region actually ran at (power-limited), the MFMA peak at that clock (peak scales with sclk:
-        # 2.5 PFLOP/s is quoted at 2.4 GHz), and the dominant kernel against it
         roof["clocks_during_timed_region"] = clocks
         peak_at = PEAK_F16_TFLOPS * clocks["sclk_mhz_mean"] / 2400.0
         roof["peak_at_measured_sclk"] = round(peak_at, 1)
@@ -295,19 +374,23 @@ def main():
     del gen
     torch.cuda.empty_cache()
 
-    # the same workload in the "f16x3" precision mode (fp32 activations, split-fp16 3-pass convs: 1e-3 at every tap)
-    exact = None
-    if not a.no_exact:
-        genx = engine.build_generator(gsd, dev, precision="f16x3")
-        ksteps = max(2, a.steps // 4)
-        dtx = timed(lambda: genx.forward(xg), ksteps, 1, dev, distributed)
-        roofx = conv_roofline(genx, xg, steps=2) if rank == 0 else None
-        exact = {"precision": "f16x3: fp32 NHWC activations, a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on fp16 MFMA, fp32 accumulate",
-                 "value": round(a.gen_batch * world * ksteps / dtx, 2), "unit": "images/s", "steps": ksteps,
-                 "ms_per_step": round(dtx / ksteps * 1e3, 3), "parity": "max|d|/max|ref| <= 1e-3 at every tap (tests/test_hip_models.py)",
-                 "roofline": roofx}
-        del genx
+    def side_mode(precision, label, parity, ksteps):
+        net = engine.build_generator(gsd, dev, precision=precision)
+        dtx = timed(lambda: net.forward(xg), ksteps, 2, dev, distributed)
+        roofx = conv_roofline(net, xg, steps=2, traffic_key="r01_pmc_traffic.json" if (precision == "f16" and a.gen_batch == 64) else None) if rank == 0 else None
+        rec = {"precision": label, "value": round(a.gen_batch * world * ksteps / dtx, 2), "unit": "images/s", "steps": ksteps,
+               "ms_per_step": round(dtx / ksteps * 1e3, 3), "parity": parity, "roofline": roofx}
+        del net
         torch.cuda.empty_cache()
+        return rec
+
+    # NOT the headline: single-pass fp16 (fastest, generator taps only within 3.5e-3) and the three-pass split (f16x3, exact to 3e-6)
+    fast = None if a.no_fast else side_mode(
+        "f16", "f16: fp16 NHWC activations, single fp16 MFMA pass, fp32 accumulate",
+        "OUTSIDE north_star's generator tolerance: max|d|/max|ref| up to 3.5e-3 pre-tanh (tests: *_f16_envelope); descriptor gates met", a.steps)
+    exact = None if a.no_exact else side_mode(
+        "f16x3", "f16x3: fp32 NHWC activations, a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on fp16 MFMA, fp32 accumulate",
+        "max|d|/max|ref| <= 1e-5 at every tap", max(2, a.steps // 4))
 
     # ---------------------------------------------------------------- secondary: GeM-R101 descriptors/s @1024^2
     secondary = None
@@ -326,9 +409,10 @@ def main():
         r_dps = n_total * a.steps / dt2
         roof2 = conv_roofline(emb, xe) if rank == 0 else None
         secondary = {"metric": "descriptors/sec GeM-ResNet101 single-scale @1024x1024", "value": round(r_dps, 2),
-                     "unit": "descriptors/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3),
+                     "unit": "descriptors/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3), "dtype": "f16",
                      "config": {"workload": "gem_resnet101 forward + GeM + L2N (+ RCCL all-gather when N>1), synthetic 3x1024x1024",
                                 "batch_per_gpu": a.r101_batch, "parallelism": "dp%d" % world},
+                     "parity": "descriptor gates met in this mode: cos >= 0.9999, |d|inf <= 1e-3 (tests/test_hip_models.py, test_hip_fullsize_properties.py)",
                      "whole_net_tflops_per_gpu": round(r_dps * R101_GFLOP_PER_IMAGE / 1e3 / world, 1),
                      "roofline": roof2}
         del emb
@@ -336,16 +420,18 @@ def main():
 
     if rank == 0:
         line = {"metric": "images/sec generator@256^2 + descriptors/sec GeM-R101@1024^2, 1/2/4/8 MI355X",
-                "value": round(gen_ips, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "value": round(gen_ips, 2), "unit": "images/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(gen_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f16", "data": "synthetic",
+                "dtype": "f16c", "data": "synthetic",
                 "config": {"workload": "cyclegan ResnetGenerator 9-block (InstanceNorm) forward, synthetic 3x256x256, random-init weights",
                            "batch_per_gpu": a.gen_batch, "global_batch": a.gen_batch * world, "parallelism": "dp%d" % world,
-                           "precision": "fp16 MFMA inputs, fp32 accumulate, fp16 NHWC activations"},
+                           "precision": "f16c: fp32 NHWC activations; conv = fp16 MFMA product (fp32 accumulate) + block-scaled fp4 x fp6 "
+                                        "correction MFMA carrying both fp16 rounding residuals; layers without a compensated kernel run the "
+                                        "three-pass f16x3 split"},
                 "whole_net_tflops_per_gpu": round(gen_tflops, 1),
-                "parity": "descriptor gates met (cos >= 0.9999, |d|inf <= 1e-3); generator image max|d|/max|ref| <= 3.5e-3 pre-tanh "
-                          "(single-pass fp16, DESIGN.md section 5); see exact_mode for the 1e-3 configuration",
-                "roofline": roof, "exact_mode": exact, "secondary": secondary}
+                "parity": "north_star gates met by this mode: generator max|d|/max|ref| <= 1e-3 at every tap and pre-tanh (measured 2.2e-4 at "
+                          "batch 64), tests/test_hip_models.py + tests/test_hip_fullsize_properties.py",
+                "roofline": roof, "fast_mode": fast, "exact_mode": exact, "secondary": secondary}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline_generator()
             if secondary is not None:

@@ -10,18 +10,36 @@ import os
 import torch
 
 
-def default_precision():
-    """'f16' (single fp16 MFMA pass, the throughput mode) unless GANDTR_HIP_PRECISION=f16x3 selects the split-fp16 mode that
-    reproduces the reference's fp32 results to 1e-3 at every layer."""
-    return os.environ.get("GANDTR_HIP_PRECISION", "f16")
+def default_precision(model_default="f16"):
+    """Conv arithmetic of the HIP path when the module does not say: GANDTR_HIP_PRECISION if set, else the model family's own
+    default -- the mode in which that family meets north_star's parity gates: "f16c" for the generators
+    (single-pass fp16 leaves their 24-layer stack at 2.5e-3 of the fp32 reference), "f16" for the embedders and HED."""
+    return os.environ.get("GANDTR_HIP_PRECISION") or model_default
 
 
 class HipBacked:
-    #: per-module override of the conv arithmetic on the HIP path: None -> default_precision()
+    #: per-module override of the conv arithmetic on the HIP path ("f16" | "f16c" | "f16x3"): None -> default_precision()
     hip_precision = None
+    #: the family default (see default_precision)
+    hip_default_precision = "f16"
 
     def _hip_precision(self):
-        return self.hip_precision or default_precision()
+        return self.hip_precision or default_precision(self.hip_default_precision)
+
+    def _hip_check_inference(self):
+        """The HIP forward returns tensors without autograd history.  A module in training mode with trainable parameters and
+        autograd enabled expects gradients: refuse.  In eval mode (how the hub returns its networks, mdir/hub/model.py:34-36) the
+        call is served, with one warning that no graph is recorded unless the caller used torch.no_grad()."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.training:
+                raise NotImplementedError("the HIP path is inference-only: call .eval() and wrap the call in torch.no_grad(); "
+                                          "training runs on the torch modules (device='cpu')")
+            if not HipBacked._warned_no_grad:
+                HipBacked._warned_no_grad = True
+                import warnings
+                warnings.warn("gandtr_amd: the HIP forward records no autograd graph; wrap inference in torch.no_grad()", stacklevel=3)
+
+    _warned_no_grad = False
 
     def _hip_device(self):
         p = next(self.parameters(), None)

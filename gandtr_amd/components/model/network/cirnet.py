@@ -87,6 +87,7 @@ class ImageRetrievalNet(HipBacked, nn.Module):
             raise NotImplementedError("HIP embedder supports GeM pooling without local/final whitening layers (hub configuration)")
         if self.meta.get("architecture") not in ("vgg16", "resnet50", "resnet101", "resnet152"):
             raise NotImplementedError("HIP embedder supports vgg16 / resnet50 / resnet101 / resnet152 trunks")
+        self._hip_check_inference()
         prec = self._hip_precision()
         net = self._hip_net(("embed", prec), lambda sd, dev: engine.build_embedder(sd, dev, precision=prec))
         return net.forward(x, scale=scale)[net.out_slot].t()      # N x D storage, D x N view (imageretrievalnet.py:123)

@@ -35,6 +35,7 @@ class HedInterpolation(HipBacked, nn.Module):
     def forward(self, x, no_sigmoid=False):
         if self._hip_device().type == "cuda":
             from .... import engine
+            self._hip_check_inference()
             prec = self._hip_precision()
             net = self._hip_net(("hed", bool(no_sigmoid), prec),
                                 lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid, precision=prec))

@@ -259,12 +259,17 @@ def generator_layout(sd):
     return norm, w0.shape[0], n_blocks, w0.shape[1], sd["model.%d.weight" % last].shape[0]
 
 
-def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precision="f16", finalize=True):
+def build_generator(sd, device, taps=(), pre_tanh=False, in_affine=None, precision="f16c", finalize=True, norm=None):
     """ResnetGenerator as a HIP graph.  External outputs: [generator output] + one per requested tap (in ``taps``
     order).  Taps follow the reference's nn.Sequential indices (p2p_networks.py:316-334); a norm-layer tap aliases the
     post-ReLU tensor because the reference's ReLUs are in-place (:272).  Tap 0 / the second reflection pad are not
     materialised on the device (padding is resolved inside the conv loader) and are not available."""
-    norm, ngf, n_blocks, in_nc, out_nc = generator_layout(sd)
+    key_norm, ngf, n_blocks, in_nc, out_nc = generator_layout(sd)
+    norm = norm or key_norm          # the module's configured norm type when the caller knows it (get_norm_layer, p2p_networks.py:23-35)
+    if norm not in ("instance", "batch"):
+        raise NotImplementedError('normalization layer [%s] is not found' % norm)          # p2p_networks.py:34
+    if norm == "batch" and key_norm != "batch":
+        raise NotImplementedError("BatchNorm without running statistics (track_running_stats=False) has no inference form on the HIP path")
     inorm = norm == "instance"
     net = HipNet(device, precision)
     tap_slots = {}

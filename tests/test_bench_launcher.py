@@ -1,0 +1,43 @@
+"""bench.py launches its own ranks for --gpus N (one process per GPU): rehearsed here without a GPU in
+--dry-run mode (gloo backend, CPU tensors, the same barrier / max-over-ranks timing and descriptor all-gather)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, check=False)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_self_launch_two_ranks_dry_run():
+    rc, lines, err = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines                       # exactly one JSON line on stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["rccl_ranks"] == 2 and doc["dry_run"] is True and doc["steps"] == 2
+    assert doc["scaling"] == "weak" and doc["higher_is_better"] is True
+
+
+def test_single_rank_dry_run_line_shape():
+    rc, lines, err = _run(["--dry-run", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    doc = json.loads(lines[-1])
+    assert doc["n_gpus"] == 1 and doc["rccl_ranks"] == 1
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "vs_baseline", "dtype", "data", "config"):
+        assert key in doc
+
+
+def test_launcher_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=False)
+    assert p.returncode == 2 and b"launcher mismatch" in p.stderr

@@ -11,29 +11,30 @@ from gandtr_amd.tools import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+@pytest.mark.parametrize("precision", ["f16c", "f16", "f16x3"])
 def test_generator_64x256_batch_independence_and_determinism(cuda_device, precision):
     """config 2 geometry (64x3x256x256).  Tile shapes and kernel variants change with the batch size (halo kernel vs generic
     implicit GEMM), so cross-batch equality is numerical, not bitwise; same-geometry runs must be bitwise identical."""
     net = engine.build_generator(synth.generator_state(0, "instance"), cuda_device, pre_tanh=True, precision=precision)
-    n = 64 if precision == "f16" else 16
+    n = 16 if precision == "f16x3" else 64
     x = synth.synth_input(40, (n, 3, 256, 256), 1.0).to(cuda_device)
     full = net.forward(x)[net.out_slot]
     again = net.forward(x)[net.out_slot]
     assert torch.equal(full, again)                                   # deterministic
     assert torch.isfinite(full).all() and full.shape == (n, 3, 256, 256)
     half = torch.cat([net.forward(x[: n // 2])[net.out_slot], net.forward(x[n // 2:])[net.out_slot]])
-    if precision == "f16":
+    if precision != "f16x3":
         assert torch.equal(half, full)                                # same kernel variants: shard concat == full batch, bitwise
     else:                                                             # 8 images fall below the halo kernel's tile threshold
         assert float((half - full).abs().max() / full.abs().max()) < 2e-5
     single = net.forward(x[5:6])[net.out_slot]
-    tol = 6e-3 if precision == "f16" else 2e-5                        # different kernel variants at batch 1 (fp16 rounding paths)
+    tol = {"f16": 6e-3, "f16c": 1e-3, "f16x3": 2e-5}[precision]     # different kernel variants at batch 1 (f16c: generic f16x3 kernels there)
     assert float((single - full[5:6]).abs().max() / full.abs().max()) < tol
     perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(cuda_device)
     assert torch.equal(net.forward(x[perm])[net.out_slot], full[perm])   # images are independent units
     # the production geometry itself (batch 64: persistent halo / transposed / stem / head kernels, every InstanceNorm folded)
-    # against the CPU oracle on two of its images -- same gates as test_hip_models.py (fp16 envelope / 1e-3 in f16x3)
+    # against the CPU oracle on two of its images -- same gates as test_hip_models.py: north_star's 1e-3 in the default f16c mode and
+    # in f16x3, the measured fp16 envelope in the opt-in single-pass mode
     from oracle import gandtr_oracle as O
     sd = synth.generator_state(0, "instance")
     for i in (5, n - 1):

@@ -1,5 +1,5 @@
 """GPU path against the committed golden vectors (outputs of the imported reference, tests/golden/make_golden.py) and the
-hub / wrapper plumbing on a cuda device.  Generator tolerances: see DESIGN.md "Precision" -- single-pass fp16 MFMA."""
+hub / wrapper plumbing on a cuda device.  The hub generators run their default "f16c" precision: 1e-3 against the reference."""
 import os
 import pickle
 
@@ -33,9 +33,9 @@ def test_generator_tiny_taps_vs_reference(cuda_device, norm):
     taps = [1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 14, 15, 17, 19, 20]
     with torch.no_grad():
         out, feats = gen(synth.synth_input(1, (2, 3, 32, 32), 1.0).to(cuda_device), layers=list(taps))
-    assert rel(out.cpu(), g["out"]) < 5e-3
+    assert rel(out.cpu(), g["out"]) < 1e-3
     for t, f in zip(taps, feats):
-        assert rel(f.cpu(), g["tap%d" % t]) < 5e-3, t
+        assert rel(f.cpu(), g["tap%d" % t]) < 1e-3, t
 
 
 @pytest.mark.parametrize("name", ["cyclegan", "hedngan"])
@@ -48,9 +48,12 @@ def test_hub_generator_on_gpu(cuda_device, name):
         y = net(x)
     assert y.is_cuda and y.shape == (4, 3, 256, 256)
     y = y.cpu()
-    # gain-0.2 init saturates tanh: compare the statistics and the sub-sampled image loosely; the tight
-    # pre-tanh comparison lives in test_hip_models.py
-    assert float((y[:, :, ::8, ::8] - torch.from_numpy(g["out_sub"])).abs().mean()) < 5e-3
+    # the reference's own output on the same seed-0 weights (tests/golden/make_golden.py).  gain-0.2 init drives |pre-tanh| to ~30
+    # (SURVEY.md D6), so a 1e-3 relative pre-tanh error may move an output near a zero crossing by up to ~3e-2; the image as a whole
+    # must agree to 1e-4 in the mean and 1e-3 at the 99.9th percentile.  (The tight per-tap comparison lives in test_hip_models.py.)
+    diff = (y[:, :, ::8, ::8] - torch.from_numpy(g["out_sub"])).abs()
+    assert float(diff.mean()) < 1e-4, float(diff.mean())
+    assert float(diff.flatten().kthvalue(int(diff.numel() * 0.999)).values) < 1e-3
 
 
 @pytest.mark.parametrize("arch,p", [("vgg16", 3.0), ("resnet101", 2.37)])
@@ -133,14 +136,18 @@ def test_chain_config5_on_gpu(cuda_device):
 
 
 def test_hub_generator_precision_switch(cuda_device, monkeypatch):
-    """GANDTR_HIP_PRECISION / Module.hip_precision select the f16x3 mode on the hub path; it must be closer to the reference"""
+    """GANDTR_HIP_PRECISION / Module.hip_precision select the conv arithmetic on the hub path: the default (f16c) and f16x3 are
+    far closer to the reference than the opt-in single-pass fp16"""
     g = load("hub_cyclegan")
     ref = torch.from_numpy(g["out_sub"])
     x = synth.synth_input(3, (4, 3, 256, 256), 1.0)
     net = hubconf.cyclegan(pretrained=False, device=cuda_device)
+    assert net.model._hip_precision() == "f16c"
     with torch.no_grad():
+        default = net(x).cpu()[:, :, ::8, ::8]
+        net.model.hip_precision = "f16"
         fast = net(x).cpu()[:, :, ::8, ::8]
         net.model.hip_precision = "f16x3"
         exact = net(x).cpu()[:, :, ::8, ::8]
-    e_fast, e_exact = float((fast - ref).abs().mean()), float((exact - ref).abs().mean())
-    assert e_exact < 2e-5 and e_exact < e_fast / 20, (e_fast, e_exact)
+    e_default, e_fast, e_exact = (float((t - ref).abs().mean()) for t in (default, fast, exact))
+    assert e_exact < 2e-5 and e_default < 1e-4 and e_default < e_fast / 5, (e_default, e_fast, e_exact)

@@ -1,6 +1,10 @@
 """GPU parity of the whole hot path (through the C ABI) against the CPU oracle on the same seeded inputs and
 synthesised weights.  Gates: generator taps/outputs max|d|/max|ref| <= 1e-3 (pre-tanh, D6);
-descriptors ||d||_inf <= 1e-3 and cosine >= 0.9999."""
+descriptors ||d||_inf <= 1e-3 and cosine >= 0.9999.
+
+The generator's DEFAULT precision is "f16c" (fp16 product + block-scaled correction product; f16x3 kernels where no compensated
+kernel applies): every test below that does not name a precision runs it and holds it to 1e-3.  Single-pass "f16" is an opt-in
+fast mode OUTSIDE that tolerance; its tests are named *_f16_envelope and assert the measured fp16 envelope only."""
 import math
 
 import pytest
@@ -29,34 +33,67 @@ def test_generator_tiny_all_taps(cuda_device, norm):
     ref, feats = O.resnet_generator(x, sd, norm, 2, taps=taps)
     net = build_generator(sd, cuda_device, taps=taps)
     outs = net.forward(x.to(cuda_device))
-    # ngf = 8 means K = 72..288 per conv: far less error averaging than the real model (K = 2304), so the tiny
-    # full-coverage net is held to 5e-3; the 1e-3 gate is applied to the full-size generator below.
-    assert _rel(outs[net.out_slot].cpu(), ref) < 5e-3
+    assert _rel(outs[net.out_slot].cpu(), ref) < 1e-3
     for t in taps:
         got = outs[net.tap_slots[t]].cpu()
         assert got.shape == feats[t].shape, t
-        assert _rel(got, feats[t]) < 5e-3, (t, _rel(got, feats[t]))
+        assert _rel(got, feats[t]) < 1e-3, (t, _rel(got, feats[t]))
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_tiny_all_taps_f16_envelope(cuda_device, norm):
+    """opt-in single-pass fp16: ngf = 8 means K = 72..288 per conv (far less error averaging than the real model): 5e-3"""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, ngf=8, n_blocks=2)
+    x = synth.synth_input(1, (2, 3, 32, 32), 1.0)
+    taps = tuple(i for i in range(1, 21) if i != 18)
+    ref, feats = O.resnet_generator(x, sd, norm, 2, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16")
+    outs = net.forward(x.to(cuda_device))
+    assert _rel(outs[net.out_slot].cpu(), ref) < 5e-3
+    for t in taps:
+        assert _rel(outs[net.tap_slots[t]].cpu(), feats[t]) < 5e-3, (t, _rel(outs[net.tap_slots[t]].cpu(), feats[t]))
 
 
 @pytest.mark.parametrize("norm,gain", [("instance", 0.02), ("instance", 0.2), ("batch", None)])
-def test_generator_full_pre_tanh(cuda_device, norm, gain):
-    """Full-size ResnetGenerator (ngf 64, 9 blocks) on 2x3x256x256; pre-tanh output (tap 26) and block taps."""
+@pytest.mark.parametrize("batch", [2, 8])
+def test_generator_full_pre_tanh(cuda_device, norm, gain, batch):
+    """Full-size ResnetGenerator (ngf 64, 9 blocks) on Nx3x256x256 in the default precision: every tap and the pre-tanh output
+    (tap 26) within north_star's 1e-3.  Batch 8 is the smallest batch at which the compensated patch kernels (conv3x3_halo_c.hip,
+    3x3 and transposed forms, InstanceNorm folded into their staging) take the resblock / up-sampling layers; batch 2 runs the
+    generic f16x3 kernels throughout."""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, norm, gain=gain or 0.02)
+    x = synth.synth_input(2, (batch, 3, 256, 256), 1.0)
+    taps = (1, 3, 9, 10, 14, 18, 21, 24, 26)
+    ref, feats = O.resnet_generator(x, sd, norm, 9, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps)
+    assert net.precision == "f16c"
+    outs = net.forward(x.to(cuda_device))
+    for t in taps:
+        r = _rel(outs[net.tap_slots[t]].cpu(), feats[t])
+        assert r < 1e-3, (t, r)
+    if gain != 0.2:     # gain 0.2 drives |pre-tanh| to ~30 (59 % of outputs saturated, SURVEY.md D6): only pre-tanh is meaningful
+        assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("norm,gain", [("instance", 0.02), ("instance", 0.2), ("batch", None)])
+def test_generator_full_pre_tanh_f16_envelope(cuda_device, norm, gain):
+    """The opt-in single-pass fp16 mode (11-bit mantissa for activations AND weights) through 24 chaotic random-weight layers: the
+    error grows from ~3e-4 at the stem to ~2.5e-3 at the pre-tanh head (DESIGN.md "Precision").  NOT north_star-compliant: the gate
+    here is the measured fp16 envelope, so that this mode cannot drift further."""
     from gandtr_amd.engine import build_generator
     sd = synth.generator_state(0, norm, gain=gain or 0.02)
     x = synth.synth_input(2, (2, 3, 256, 256), 1.0)
     taps = (9, 14, 18, 24, 26)
     ref, feats = O.resnet_generator(x, sd, norm, 9, taps=taps)
-    net = build_generator(sd, cuda_device, taps=taps)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16")
     outs = net.forward(x.to(cuda_device))
-    # Single-pass fp16 MFMA (11-bit mantissa for activations AND weights) through 24 chaotic random-weight layers: the
-    # error grows from ~3e-4 at the stem to ~2.5e-3 at the pre-tanh head (CPU emulation of the roundings in DESIGN.md
-    # "Precision" reproduces these numbers).  north_star's 1e-3 is met up to the first residual blocks only; the gate
-    # here is the measured fp16 envelope (3.5e-3), tracked as an open item in DESIGN.md.
     gate = {9: 1e-3, 14: 3e-3, 18: 3e-3, 24: 3.5e-3, 26: 3.5e-3}
     for t in taps:
         r = _rel(outs[net.tap_slots[t]].cpu(), feats[t])
         assert r < gate[t], (t, r)
-    if gain != 0.2:     # gain 0.2 drives |pre-tanh| to ~30 (59 % of outputs saturated, SURVEY.md D6): only pre-tanh is meaningful
+    if gain != 0.2:
         assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 2e-2
 
 
@@ -176,7 +213,7 @@ def test_generator_ragged_sizes(cuda_device, norm, shape):
     sd = synth.generator_state(0, norm, ngf=16, n_blocks=3)
     x = synth.synth_input(11, shape, 1.0)
     ref = O.resnet_generator(x, sd, norm, 3, pre_tanh=True)
-    for prec, tol in (("f16", 5e-3), ("f16x3", 1e-4)):
+    for prec, tol in (("f16c", 1e-3), ("f16", 5e-3), ("f16x3", 1e-4)):
         net = build_generator(sd, cuda_device, pre_tanh=True, precision=prec)
         got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
         assert got.shape == ref.shape
