@@ -73,8 +73,8 @@ def test_generator_full_pre_tanh(cuda_device, norm, gain, batch):
     for t in taps:
         r = _rel(outs[net.tap_slots[t]].cpu(), feats[t])
         assert r < 1e-3, (t, r)
-    if gain != 0.2:     # gain 0.2 drives |pre-tanh| to ~30 (59 % of outputs saturated): only pre-tanh is meaningful
-        assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3
+    # the image itself: |d tanh| <= |d pre-tanh| <= 1e-3 * max|pre-tanh|
+    assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(feats[26].abs().max()))
 
 
 @pytest.mark.parametrize("norm,gain", [("instance", 0.02), ("instance", 0.2), ("batch", None)])
