@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void
 _LIB_PATH = os.environ.get("GANDTR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgandtr_hip.so")
 _lib = None
 
-GDT_OK, GDT_ERR_INVALID, GDT_ERR_HIP, GDT_ERR_WORKSPACE = 0, 1, 2, 3
+GDT_OK, GDT_ERR_INVALID, GDT_ERR_HIP, GDT_ERR_WORKSPACE, GDT_ERR_NOT_CONVERGED = 0, 1, 2, 3, 4
 
 
 class ConvDesc(ctypes.Structure):
@@ -49,10 +49,12 @@ SIGNATURES = {
     "gdt_net_profile_read": (c_int, [c_void_p, c_int, _IP, _IP, _IP, POINTER(c_double), POINTER(c_double)]),
     "gdt_ms_aggregate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gdt_whiten": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gdt_whiten_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gdt_retrieval_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_retrieval_scores_ranks": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                            c_void_p]),
     "gdt_l2n_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "gdt_gem_l2n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gdt_mfma_only_tflops": (c_int, [c_int, POINTER(c_double), c_void_p]),
     "gdt_ingest_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_ingest_resize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_void_p, c_void_p,

@@ -34,14 +34,51 @@ class Compose:
             return inference(tensor, **tensor_params)
         if outputmodel is None:
             outputmodel = inference
+        active, folded = self._fold_input_wrappers(outputmodel)
         metas = []
-        for w in self.wrappers:
+        for w in active:
             tensor, meta = w.preprocess(tensor, outputmodel)
             metas.append(meta)
-        tensor = inference(tensors.to_device(tensor, self.device), **tensor_params)
-        for w, meta in reversed(list(zip(self.wrappers, metas))):
+        if folded is None:
+            tensor = inference(tensors.to_device(tensor, self.device), **tensor_params)
+        else:                               # the trailing per-channel input wrappers run inside the model's HIP input-pack kernel
+            previous, outputmodel.input_transform = outputmodel.input_transform, folded
+            try:
+                tensor = inference(tensors.to_device(tensor, self.device), **tensor_params)
+            finally:
+                outputmodel.input_transform = previous
+        for w, meta in reversed(list(zip(active, metas))):
             tensor = w.postprocess(tensor, outputmodel, meta)
         return tensor
+
+    def _fold_input_wrappers(self, outputmodel):
+        """(wrappers to run on the host, (perm, scale, shift) or None).  A model on a HIP device that declares
+        ``accepts_input_transform`` takes the longest trailing run of pure per-channel input wrappers (channel permutation, mean / std
+        re-normalisation: RgbToBgrPre, MeanStdPre -- mdir/components/data/wrapper.py:351-364, :182-194) as ONE transform
+        ``y[c] = x[perm[c]] * scale[c] + shift[c]`` applied while its input is packed: no torch op on the data path."""
+        if not getattr(outputmodel, "accepts_input_transform", False):
+            return self.wrappers, None
+        dev = getattr(outputmodel, "_hip_device", None)
+        if dev is None or dev().type != "cuda":
+            return self.wrappers, None
+        cut = len(self.wrappers)
+        while cut > 0 and self.wrappers[cut - 1].input_transform() is not None:
+            cut -= 1
+        if cut == len(self.wrappers):
+            return self.wrappers, None
+        perm, scale, shift = None, None, None
+        for w in self.wrappers[cut:]:
+            kind, *args = w.input_transform()
+            if perm is None:
+                n = len(args[0])
+                perm, scale, shift = list(range(n)), [1.0] * n, [0.0] * n
+            if kind == "perm":
+                p = args[0]
+                perm, scale, shift = [perm[i] for i in p], [scale[i] for i in p], [shift[i] for i in p]
+            else:
+                s2, h2 = args
+                scale, shift = [a * b for a, b in zip(scale, s2)], [a * b + c for a, b, c in zip(shift, s2, h2)]
+        return self.wrappers[:cut], (tuple(perm), tuple(scale), tuple(shift))
 
     def __repr__(self):
         inner = "\n" + "".join("    %s\n" % w for w in self.wrappers) if self.wrappers else ""
@@ -57,6 +94,11 @@ class Wrapper:
 
     def postprocess(self, tensor, _outputmodel, _metadata):
         return tensor
+
+    def input_transform(self):
+        """("perm", [..]) or ("affine", scale, shift) when the wrapper is a pure per-channel transform of the model INPUT with an
+        identity postprocess (then a HIP model can apply it while packing its input, Compose._fold_input_wrappers); else None."""
+        return None
 
 
 def _on_hip(t):
@@ -99,6 +141,10 @@ class MeanStdPost(Wrapper):
 
 
 class MeanStdPre(MeanStdPost):
+    def input_transform(self):
+        scale, shift = self.affine()
+        return ("affine", scale, shift)
+
     def preprocess(self, tensor, _outputmodel):
         if isinstance(tensor, list):
             return [self.preprocess(x, _outputmodel) for x in tensor]
@@ -271,6 +317,9 @@ class ClahePost(Wrapper):
 
 
 class RgbToBgrPre(Wrapper):
+    def input_transform(self):
+        return ("perm", [2, 1, 0])
+
     def preprocess(self, tensor, _outputmodel):
         if isinstance(tensor, list):
             return [self.preprocess(x, _outputmodel) for x in tensor], None

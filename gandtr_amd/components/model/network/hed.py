@@ -12,6 +12,8 @@ BLOCKS = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512
 
 class HedInterpolation(HipBacked, nn.Module):
     meta = {"in_channels": 3, "out_channels": 1}
+    #: on a HIP device the wrapper chain hands its trailing per-channel input wrappers over as ``input_transform``
+    accepts_input_transform = True
 
     def __init__(self, pretrained=None):
         super().__init__()
@@ -25,7 +27,8 @@ class HedInterpolation(HipBacked, nn.Module):
         for i, chans in enumerate(BLOCKS):
             setattr(self, "score%d" % (i + 1), nn.Conv2d(chans[-1], 1, kernel_size=1))
         self.fusion = nn.Sequential(nn.Conv2d(5, 1, kernel_size=1))
-        # HIP input transform folded into the pack kernel (set by wrappers-aware callers): (perm, scale, shift)
+        # per-channel input transform (perm, scale, shift) applied inside the HIP input-pack kernel; set for the duration of a call by
+        # Compose when the trailing wrappers are RgbToBgrPre / MeanStdPre (components/data/wrapper.py, _fold_input_wrappers)
         self.input_transform = None
         if pretrained:
             from ....tools.utils import fs_open
@@ -37,8 +40,10 @@ class HedInterpolation(HipBacked, nn.Module):
             from .... import engine
             self._hip_check_inference()
             prec = self._hip_precision()
-            net = self._hip_net(("hed", bool(no_sigmoid), prec),
-                                lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid, precision=prec))
+            tr = self.input_transform
+            net = self._hip_net(("hed", bool(no_sigmoid), prec, tr),
+                                lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid, precision=prec, perm=None if tr is None else list(tr[0]),
+                                                                 in_affine=None if tr is None else (list(tr[1]), list(tr[2]))))
             return net.forward(x)[net.out_slot]
         size = (x.size(2), x.size(3))
         feats, h = [], x

@@ -15,10 +15,12 @@ int gdt_k_instance_norm_stats(const void* x, int f32, int fused, float* partial,
 int gdt_k_maxpool(const void* x, void* y, int f32, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st);
 int gdt_k_gem_l2n(const void* x, int f32, float* pooled, float* out, int N, int HW, int D, float p, float eps_gem, float eps_l2,
                   hipStream_t st);
+int gdt_k_gem_l2n_nchw(const float* x, float* pooled, float* out, int N, int D, int HW, float p, float eps_gem, float eps_l2, hipStream_t st);
 int gdt_k_l2n_rows(const float* x, float* y, int N, int D, float eps, hipStream_t st);
 int gdt_k_ms_aggregate(const float* x, float* y, int S, int N, int D, float msp, hipStream_t st);
 int gdt_k_whiten(const float* P, const float* m, const float* v, float* tmp, float* out, int N, int D, int dims,
                  hipStream_t st);
+int gdt_k_whiten_f64(const double* P, const double* m, const double* v, double* tmp, double* out, int N, int D, int dims, hipStream_t st);
 int gdt_k_unpack_output(const void* x, int f32, float* y, const float* bias, int N, int HW, int C, hipStream_t st);
 int gdt_k_rowsplit_combine(const void* P, int f32, const float* bias, float* out, int N, int H, int W, int cp, int cout, int kw,
                            int pad, int reflect, int act, hipStream_t st);

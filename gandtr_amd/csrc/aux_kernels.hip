@@ -269,6 +269,22 @@ __global__ __launch_bounds__(256) void gem_kernel(const T* __restrict__ x, float
     }
 }
 
+// GeM over NCHW fp32 feature maps (the reference layout, cirtorch layers/functional.py:21-22): one wavefront per (n, c) plane, lanes
+// stride over the H*W contiguous pixels, butterfly reduction; pooled[n][c] = (mean clamp(x, eps)^p)^(1/p)
+__global__ __launch_bounds__(256) void gem_nchw_kernel(const float* __restrict__ x, float* __restrict__ pooled, long planes, int HW, float p, float eps) {
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const float* xp = x + plane * HW;
+    const bool cube = (p == 3.0f);
+    float s = 0.f;
+    for (int i = threadIdx.x & 63; i < HW; i += 64) {
+        const float f = fmaxf(xp[i], eps);
+        s += cube ? f * f * f : powf(f, p);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) pooled[plane] = powf(s / HW, 1.0f / p);
+}
+
 // y[n][:] = x[n][:] / (||x[n]||_2 + eps); one workgroup per row
 __global__ __launch_bounds__(256) void l2n_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int D, float eps) {
     __shared__ float red[4];
@@ -314,6 +330,33 @@ __global__ __launch_bounds__(256) void whiten_matvec_kernel(const float* __restr
     for (int d = lane; d < D; d += 64) s += pr[d] * (vr[d] - m[d]);
     s = wave_sum(s);
     if (lane == 0) X[(long)n * dims + r] = s;
+}
+
+// float64 form of the two kernels above: the reference's `whiten` STAGE applies the learned whitening with numpy in float64
+// (whitenapply, cirtorch/utils/whiten.py:4-12: P is float64, so X - m and the product are promoted)
+__global__ __launch_bounds__(256) void whiten_matvec_f64_kernel(const double* __restrict__ P, const double* __restrict__ m,
+                                                                const double* __restrict__ v, double* __restrict__ X, int D, int dims) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y, lane = threadIdx.x & 63;
+    if (r >= dims) return;
+    const double* pr = P + (long)r * D;
+    const double* vr = v + (long)n * D;
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) s += pr[d] * (vr[d] - m[d]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) X[(long)n * dims + r] = s;
+}
+__global__ __launch_bounds__(256) void l2n_rows_f64_kernel(const double* __restrict__ x, double* __restrict__ y, int D, double eps) {
+    __shared__ double red[4];
+    const double* xr = x + (long)blockIdx.x * D;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < D; i += 256) s += xr[i] * xr[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]) + eps;
+    for (int i = threadIdx.x; i < D; i += 256) y[(long)blockIdx.x * D + i] = xr[i] / nrm;
 }
 
 // ------------------------------------------------------------------------------------------------ taps / outputs
@@ -521,6 +564,15 @@ int gdt_k_gem_l2n(const void* x, int f32, float* pooled, float* out, int N, int 
     return GDT_OK;
 }
 
+int gdt_k_gem_l2n_nchw(const float* x, float* pooled, float* out, int N, int D, int HW, float p, float eps_gem, float eps_l2, hipStream_t st) {
+    const long planes = (long)N * D;
+    hipLaunchKernelGGL(gem_nchw_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, x, pooled, planes, HW, p, eps_gem);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)pooled, out, D, eps_l2);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
 int gdt_k_l2n_rows(const float* x, float* y, int N, int D, float eps, hipStream_t st) {
     hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, x, y, D, eps);
     GDT_CHECK_HIP(hipGetLastError());
@@ -539,6 +591,14 @@ int gdt_k_whiten(const float* P, const float* m, const float* v, float* tmp, flo
     hipLaunchKernelGGL(whiten_matvec_kernel, dim3((dims + 3) / 4, N), dim3(256), 0, st, P, m, v, tmp, D, dims);
     GDT_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(l2n_rows_kernel, dim3(N), dim3(256), 0, st, (const float*)tmp, out, dims, 1e-6f);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_k_whiten_f64(const double* P, const double* m, const double* v, double* tmp, double* out, int N, int D, int dims, hipStream_t st) {
+    hipLaunchKernelGGL(whiten_matvec_f64_kernel, dim3((dims + 3) / 4, N), dim3(256), 0, st, P, m, v, tmp, D, dims);
+    GDT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(l2n_rows_f64_kernel, dim3(N), dim3(256), 0, st, (const double*)tmp, out, dims, 1e-6);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

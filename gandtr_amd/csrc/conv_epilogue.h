@@ -55,7 +55,8 @@ __device__ __forceinline__ void conv_epilogue_f16(const ConvLaunch& d, const f32
 #pragma unroll
         for (int w = 0; w < WPR; ++w) { s1 += sl[((rec * WPR + w) * BN + col) * 2 + 0]; s2 += sl[((rec * WPR + w) * BN + col) * 2 + 1]; }
         const int gcol = tile_n * BN + col;
-        if (gcol < d.Cout) {
+        // (a 256-row tile whose second half lies past M -- M % 256 == 128 -- has no record slot: the slab holds M / 128 records)
+        if (gcol < d.Cout && tile_m * RT + rec < d.M / 128) {
             float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * RT + rec) * 2) * d.Cout + gcol;
             dst[0] = s1; dst[d.Cout] = s2;
         }

@@ -18,6 +18,9 @@ void gdt_set_error(const std::string& msg);
 #define GDT_ERR_INVALID 1
 #define GDT_ERR_HIP 2
 #define GDT_ERR_WORKSPACE 3
+#ifndef GDT_ERR_NOT_CONVERGED
+#define GDT_ERR_NOT_CONVERGED 4
+#endif
 
 #define GDT_CHECK_HIP(expr)                                                                     \
     do {                                                                                        \

@@ -1130,6 +1130,17 @@ int gdt_whiten(const float* P, const float* m, const float* v, float* tmp, float
     return gdt_k_whiten(P, m, v, tmp, out, n, d, dims, (hipStream_t)stream);
 }
 
+int gdt_whiten_f64(const double* P, const double* m, const double* v, double* tmp, double* out, int n, int d, int dims, void* stream) {
+    GDT_REQUIRE(P && m && v && tmp && out && n >= 1 && d >= 1 && dims >= 1 && dims <= d, "whiten arguments");
+    return gdt_k_whiten_f64(P, m, v, tmp, out, n, d, dims, (hipStream_t)stream);
+}
+
+int gdt_gem_l2n(const float* fmap, int n, int d, int h, int w, float p, float eps_gem, float eps_l2, float* pooled, float* out, void* stream) {
+    GDT_REQUIRE(fmap && pooled && out && n >= 1 && d >= 1 && h >= 1 && w >= 1 && p > 0.f, "gem_l2n arguments");
+    GDT_REQUIRE((long)h * w < (1l << 31), "feature map too large");
+    return gdt_k_gem_l2n_nchw(fmap, pooled, out, n, d, h * w, p, eps_gem, eps_l2, (hipStream_t)stream);
+}
+
 int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream) {
     GDT_REQUIRE(x && y && n >= 1 && d >= 1, "l2n arguments");
     return gdt_k_l2n_rows(x, y, n, d, eps, (hipStream_t)stream);

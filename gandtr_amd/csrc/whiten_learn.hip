@@ -414,6 +414,7 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
     // preferred: one-sided Jacobi on G = P0 Lc (needs C positive definite and both columns of a pair in LDS)
     int sweeps = 0;
     int c_failed = 1;
+    bool converged = false;
     if ((size_t)2 * d * sizeof(double) <= 64 * 1024) {
         hipLaunchKernelGGL(add_diag_copy_kernel, dim3(dd_blocks), dim3(256), 0, st, T1, A, d, 0.0);
         rc = cholesky_inplace(st, A, d, flag, c_failed);
@@ -429,7 +430,7 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
             int changed = 0;
             GDT_CHECK_HIP(hipMemcpyAsync(&changed, flag, sizeof(int), hipMemcpyDeviceToHost, st));
             GDT_CHECK_HIP(hipStreamSynchronize(st));
-            if (!changed) { ++sweeps; break; }
+            if (!changed) { ++sweeps; converged = true; break; }
         }
         hipLaunchKernelGGL(row_norm2_kernel, dim3(d), dim3(256), 0, st, V, d, cs);                              // cs = eigenvalues (unordered)
         hipLaunchKernelGGL(rank_desc_kernel, dim3((d + 255) / 256), dim3(256), 0, st, cs, (size_t)1, d, order, eig_out);
@@ -446,7 +447,7 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
             double h[2];
             GDT_CHECK_HIP(hipMemcpyAsync(h, red, sizeof(h), hipMemcpyDeviceToHost, st));
             GDT_CHECK_HIP(hipStreamSynchronize(st));
-            if (!(h[0] > 1e-26 * h[1])) break;                                                     // off-diagonal norm below 1e-13 of the diagonal's
+            if (!(h[0] > 1e-26 * h[1])) { converged = true; break; }                               // off-diagonal norm below 1e-13 of the diagonal's
             for (int r = 0; r < d - 1; ++r) {
                 hipLaunchKernelGGL(jacobi_angles_kernel, dim3((d / 2 + 255) / 256), dim3(256), 0, st, A, d, r, cs);
                 hipLaunchKernelGGL(jacobi_rows_kernel, dim3((d + 255) / 256, d / 2), dim3(256), 0, st, A, d, r, cs);
@@ -461,6 +462,10 @@ int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec
     GDT_CHECK_HIP(hipGetLastError());
     GDT_CHECK_HIP(hipStreamSynchronize(st));
     if (info) { info[0] = jitter_steps; info[1] = c_failed ? -sweeps : sweeps; }      // negative: the two-sided fallback ran
+    if (!converged) {          // the outputs are written (best effort), but the caller must not take them for an eigen-decomposition
+        gdt_set_error("whiten_learn: the Jacobi eigensolver stopped at its sweep cap (" + std::to_string(sweeps) + " sweeps) without converging");
+        return GDT_ERR_NOT_CONVERGED;
+    }
     return GDT_OK;
 }
 

@@ -424,20 +424,42 @@ def ms_aggregate(x, msp):
     return y
 
 
-def whiten(v, P, m, dims=None):
-    """v: [N][D], P: [D][D], m: [D] or [D][1] (fp32 cuda) -> [N][dims]  (wrapper.py:320-322, batched)."""
+def whiten(v, P, m, dims=None, float64=False):
+    """v: [N][D], P: [D][D], m: [D] or [D][1] (cuda) -> [N][dims]  (wrapper.py:320-322, batched).  ``float64``: the arithmetic of the
+    reference's ``whiten`` stage (numpy float64, mdir/stages/whiten.py:20-23) instead of the float32 of the inference wrapper."""
     lib = _hip.load()
-    v = v.contiguous().float()
-    P = P.contiguous().float()
-    m = m.contiguous().float().reshape(-1)
+    dt = torch.float64 if float64 else torch.float32
+    v = v.contiguous().to(dt)
+    P = P.contiguous().to(dt)
+    m = m.contiguous().to(dt).reshape(-1)
     n, d = v.shape
     dims = int(dims or P.shape[0])
-    tmp = torch.empty((n, dims), dtype=torch.float32, device=v.device)
-    out = torch.empty((n, dims), dtype=torch.float32, device=v.device)
+    tmp = torch.empty((n, dims), dtype=dt, device=v.device)
+    out = torch.empty((n, dims), dtype=dt, device=v.device)
     with torch.cuda.device(v.device):
+        if float64:
+            _hip.check(lib.gdt_whiten_f64(P.data_ptr(), m.data_ptr(), v.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, d, dims,
+                                          torch.cuda.current_stream(v.device).cuda_stream))
+            return out
         _hip.check(lib.gdt_whiten(P.data_ptr(), m.data_ptr(), v.data_ptr(), tmp.data_ptr(), out.data_ptr(), n, d, dims,
                                   torch.cuda.current_stream(v.device).cuda_stream))
     return out
+
+
+def gem_l2n(fmap, p=3.0, eps_gem=1e-6, eps_l2=1e-6):
+    """fmap: N x D x h x w fp32 cuda (reference layout).  Returns (gem N x D x 1 x 1, l2n(gem) N x D x 1 x 1):
+    cirtorch layers/functional.py:21-22, :130-131."""
+    lib = _hip.load()
+    if not fmap.is_cuda or fmap.dim() != 4:
+        raise ValueError("gem_l2n needs an N x D x h x w tensor on a HIP device")
+    fmap = fmap.contiguous().float()
+    n, d, h, w = fmap.shape
+    pooled = torch.empty((n, d), dtype=torch.float32, device=fmap.device)
+    out = torch.empty((n, d), dtype=torch.float32, device=fmap.device)
+    with torch.cuda.device(fmap.device):
+        _hip.check(lib.gdt_gem_l2n(fmap.data_ptr(), n, d, h, w, float(p), eps_gem, eps_l2, pooled.data_ptr(), out.data_ptr(),
+                                   torch.cuda.current_stream(fmap.device).cuda_stream))
+    return pooled.view(n, d, 1, 1), out.view(n, d, 1, 1)
 
 
 def l2n_rows(x, eps=1e-6):

@@ -11,6 +11,8 @@ class Checkpoints:
         if directory is None:
             return None
         with fs_open(str(directory)) as handle:
-            checkpoint = torch.load(handle, map_location="cpu", weights_only=False)
+            # the payload is dicts / lists / strings / numbers / tensors: the restricted loader reads it (no arbitrary unpickling of a
+            # file that may have come over plain http, hub/model.py BASE_URL)
+            checkpoint = torch.load(handle, map_location="cpu", weights_only=True)
         assert "net" not in checkpoint.get("_networks_included", {})
         return {"net": checkpoint, **checkpoint.pop("_networks_included", {})}

@@ -1,7 +1,18 @@
-"""Network containers -- host mirror of mdir/learning/network.py: Network :20-95, SingleNetwork :101-292,
-SequentialNetwork :635-744, CirSequentialNetwork :747-753, NETWORKS :907-918, initialize_network :920-926.
-Only the inference call path is mirrored (training topologies are out of scope)."""
-import abc
+"""Inference containers of the hot path, written against the drop-in contract of SURVEY.md section 8b (the reference interface is
+mdir/learning/network.py: Network :20-95, SingleNetwork :101-292, SequentialNetwork :635-744, CirSequentialNetwork :747-753,
+NETWORKS :907-918, initialize_network :920-926).
+
+What the contract fixes, and nothing more is kept:
+  * construction from a params dict (``type``, ``model``, ``runtime``, ``initialize`` | ``path``) or from a saved state
+    (``{"net": {"type", "frozen", "network_params", "model_state"}}``), through the registries ``NETWORKS`` / ``MODEL_LABELS`` /
+    ``WRAPPERS_LABELS``;
+  * the attribute surface the hub, the stages and user code touch: ``model, wrappers, network_params, meta, stage, device, frozen``
+    (+ ``transform`` attached by the hub), ``__call__/forward/forward_batch/eval/train/freeze/parameters/state_dict/overlay_*``;
+  * the call path: stage-dependent wrapper chain around ``model(x)``; a list input is a Python loop of forwards; the augment ->
+    embed chain feeds one network's output to the next and hoists the last network's wrappers to the container;
+  * the reference's error behaviour: ``AssertionError`` for unknown runtime keys / left-over params, ``KeyError`` for unknown types.
+Training topologies (network sets, multi-head, global-local) are out of scope.
+"""
 import copy
 import time
 from collections import namedtuple
@@ -15,60 +26,75 @@ from ..components.model.network._hipbacked import ScaledInput
 from ..tools import tensors
 from ..tools.utils import fs_open, indent
 
+TRAIN, EVAL = "train", "eval"
+_RUNTIME_KEYS = {"data", "wrappers", "frozen", "model"}
+_DATA_KEYS = {"mean_std", "transforms"}
 
-def _plain(x):
+
+def _wrapper_chains(spec, device):
+    """``{"train": Compose, "eval": Compose}`` from one spec for both stages or a dict with exactly those two keys."""
+    if isinstance(spec, dict):
+        assert spec.keys() == {TRAIN, EVAL}, spec.keys()
+        return {stage: initialize_wrappers(spec[stage], device) for stage in (TRAIN, EVAL)}
+    return {stage: initialize_wrappers(spec, device) for stage in (TRAIN, EVAL)}
+
+
+def _as_model_input(x):
     return x if isinstance(x, ScaledInput) else tensors.as_tensor(x)
 
 
-class Network(abc.ABC):
-    TRAIN = "train"
-    EVAL = "eval"
+def _load_torch(path):
+    """checkpoint payloads are dicts / lists / strings / tensors: no arbitrary unpickling"""
+    with fs_open(path) as handle:
+        return torch.load(handle, map_location="cpu", weights_only=True)
 
-    def __init__(self, frozen, model=None):
-        self.stage = None
-        self.frozen = frozen
-        self.model = model
-        if frozen:
-            self.eval()
+
+class Network:
+    """Stage bookkeeping shared by the containers.  ``stage`` selects the wrapper chain; a frozen network stays in eval mode."""
+
+    TRAIN, EVAL = TRAIN, EVAL
+
+    stage = None
+    frozen = False
+    model = None
 
     def __call__(self, image):
         return self.forward(image)
 
-    @abc.abstractmethod
     def forward(self, image):
-        ...
+        raise NotImplementedError
 
-    @staticmethod
-    def initialize_wrappers(wrappers, device):
-        if isinstance(wrappers, dict):
-            assert wrappers.keys() == {"train", "eval"}, wrappers.keys()
-            return {x: initialize_wrappers(wrappers[x], device) for x in wrappers}
-        return {x: initialize_wrappers(wrappers, device) for x in ["train", "eval"]}
+    # kept as a static method: the reference exposes it under this name
+    initialize_wrappers = staticmethod(_wrapper_chains)
+
+    def _members(self):
+        return (self.model,)
 
     def train(self):
-        if not self.frozen:
-            self.model.train()
-            self.stage = Network.TRAIN
+        if self.frozen:
+            return self
+        for m in self._members():
+            m.train()
+        self.stage = TRAIN
         return self
 
     def eval(self):
-        self.model.eval()
-        self.stage = Network.EVAL
+        for m in self._members():
+            m.eval()
+        self.stage = EVAL
         return self
 
     def freeze(self, net="net"):
         assert net == "net"
         self.frozen = True
-        self.eval()
-        return self
+        return self.eval()
 
     def parameters(self, optimizer_opts, net="net"):
         assert net == "net"
         if self.frozen:
             return []
-        if hasattr(self.model, "parameter_groups"):
-            return self.model.parameter_groups(optimizer_opts)
-        return self.model.parameters()
+        groups = getattr(self.model, "parameter_groups", None)
+        return groups(optimizer_opts) if groups else self.model.parameters()
 
     def set_meta(self, meta):
         self.meta = meta
@@ -77,96 +103,114 @@ class Network(abc.ABC):
 
 
 class SingleNetwork(Network):
-    """model + stage-dependent wrappers + params (``network_params.model`` / ``network_params.runtime``)."""
+    """One model, its wrapper chains and the params it was built from."""
 
     NetworkParams = namedtuple("NetworkParams", ["model", "runtime"])
 
     def __init__(self, model, network_params, device, frozen):
+        runtime = network_params.runtime
+        unknown = runtime.keys() - _RUNTIME_KEYS
+        assert not unknown, unknown
+        unknown = runtime.get("data", {}).keys() - _DATA_KEYS
+        assert not unknown, unknown
         self.meta = model.meta if model.meta else {}
-        if "model" in network_params.runtime:
-            model.runtime = network_params.runtime["model"]
+        if "model" in runtime:
+            model.runtime = runtime["model"]
         self.network_params = network_params
-        self.wrappers = self.initialize_wrappers(network_params.runtime.get("wrappers", ""), device)
-        super().__init__(network_params.runtime.get("frozen", False) or frozen, model.to(device))
         self.device = device
-        extra = network_params.runtime.keys() - {"data", "wrappers", "frozen", "model"}
-        assert not extra, extra
-        extra = network_params.runtime.get("data", {}).keys() - {"mean_std", "transforms"}
-        assert not extra, extra
+        self.wrappers = _wrapper_chains(runtime.get("wrappers", ""), device)
+        self.model = model.to(device)
+        self.frozen = bool(runtime.get("frozen", False) or frozen)
+        if self.frozen:
+            self.eval()
 
+    # ---- call path
     def forward(self, image, **params):
-        return self.wrappers[self.stage](image, self.forward_batch, outputmodel=self.model, tensor_params=params)
+        chain = self.wrappers[self.stage]
+        return chain(image, self.forward_batch, outputmodel=self.model, tensor_params=params)
 
     def forward_batch(self, images, **params):
         if images is None:
             return None
         if isinstance(images, list):
-            return [self.model(_plain(x), **params) if x is not None else None for x in images]
-        return self.model(_plain(images), **params)
+            return [None if x is None else self.model(_as_model_input(x), **params) for x in images]
+        return self.model(_as_model_input(images), **params)
 
+    # ---- construction
     @classmethod
     def initialize(cls, params, device):
         path = params.pop("path", None)
-        if not path:
+        if path:
+            model, network_params = cls._from_checkpoint_file(path, params)
+        else:
             network_params = cls.NetworkParams(params.pop("model"), params.pop("runtime"))
             model = model_registry.initialize_model(copy.deepcopy(network_params.model))
-            init = params.pop("initialize")
-            if init and isinstance(init, str):
-                with fs_open(init) as handle:
-                    model.load_state_dict(torch.load(handle))
-            elif init and init["weights"] != "default":
-                weights, seed = init.pop("weights"), init.pop("seed")
-                torch.manual_seed(seed if seed is not None else time.time())
-                model.apply(weight_initialization.initialize_weights(weights, init))
-        else:
-            with fs_open(path) as handle:
-                checkpoint = torch.load(handle, map_location="cpu")
-            runtime = params.pop("runtime")
-            ck_runtime = checkpoint["network_params"]["runtime"]
-            if runtime == "load_from_checkpoint":
-                runtime = ck_runtime
-            else:
-                runtime = {k: (v if v != "load_from_checkpoint" else ck_runtime[k]) for k, v in runtime.items()}
-            network_params = cls.NetworkParams(checkpoint["network_params"]["model"], runtime)
-            model = model_registry.initialize_model(copy.deepcopy(network_params.model))
-            model.load_state_dict(checkpoint["model_state"])
-            params.pop("initialize", None)
-            if "model" in params:
-                pm = params.pop("model")
-                assert pm == checkpoint["network_params"]["model"], "{} != {}".format(pm, checkpoint["network_params"]["model"])
+            cls._initialize_weights(model, params.pop("initialize"))
         assert not params, params.keys()
         return cls(model, network_params, device=device, frozen=False)
 
-    def overlay_params(self, new_params, device=None):
-        if not new_params:
-            return self
-        new_params["runtime"]["frozen"] = True
-        network_params = self.NetworkParams(self.network_params.model, new_params.pop("runtime"))
-        assert not new_params
-        return self.__class__(self.model, network_params, device or self.device, frozen=True)
+    @staticmethod
+    def _initialize_weights(model, init):
+        """``initialize``: falsy -> the modules' own default init; a path -> a plain state dict; a dict -> seeded registry init."""
+        if not init:
+            return
+        if isinstance(init, str):
+            model.load_state_dict(_load_torch(init))
+            return
+        if init["weights"] == "default":
+            return
+        scheme, seed = init.pop("weights"), init.pop("seed")
+        torch.manual_seed(seed if seed is not None else time.time())
+        model.apply(weight_initialization.initialize_weights(scheme, init))
 
-    def overlay_model(self, new_model, device=None):
-        return self.__class__(new_model, self.network_params, device or self.device, frozen=True)
-
-    def state_dict(self):
-        return {"net": {"type": self.__class__.__name__, "frozen": self.frozen,
-                        "network_params": self.network_params._asdict(), "model_state": self.model.state_dict()}}
+    @classmethod
+    def _from_checkpoint_file(cls, path, params):
+        checkpoint = _load_torch(path)
+        saved = checkpoint["network_params"]
+        runtime = params.pop("runtime")
+        if runtime == "load_from_checkpoint":
+            runtime = saved["runtime"]
+        else:
+            runtime = {k: (saved["runtime"][k] if v == "load_from_checkpoint" else v) for k, v in runtime.items()}
+        params.pop("initialize", None)
+        if "model" in params:
+            given = params.pop("model")
+            assert given == saved["model"], "{} != {}".format(given, saved["model"])
+        model = model_registry.initialize_model(copy.deepcopy(saved["model"]))
+        model.load_state_dict(checkpoint["model_state"])
+        return model, cls.NetworkParams(saved["model"], runtime)
 
     @classmethod
     def initialize_from_state(cls, state_dict, device, params, runtime):
         assert state_dict.keys() == {"net"}, state_dict.keys()
-        checkpoint = state_dict["net"]
-        assert checkpoint.keys() == {"type", "frozen", "network_params", "model_state"}, checkpoint.keys()
-        network_params = cls.NetworkParams(**checkpoint["network_params"])
-        assert checkpoint["type"] == cls.__name__, checkpoint["type"]
+        saved = state_dict["net"]
+        assert saved.keys() == {"type", "frozen", "network_params", "model_state"}, saved.keys()
+        assert saved["type"] == cls.__name__, saved["type"]
+        network_params = cls.NetworkParams(**saved["network_params"])
         if params is not None and "path" not in params:
             del params["initialize"]
             assert network_params._asdict() == params, "%s != %s" % (network_params._asdict(), params)
         model = model_registry.initialize_model(copy.deepcopy(network_params.model))
-        model.load_state_dict(checkpoint["model_state"])
+        model.load_state_dict(saved["model_state"])
         if runtime:
             network_params.runtime.update(runtime)
-        return cls(model, network_params, device=device, frozen=checkpoint["frozen"])
+        return cls(model, network_params, device=device, frozen=saved["frozen"])
+
+    # ---- (de)serialisation, overlays
+    def state_dict(self):
+        return {"net": {"type": type(self).__name__, "frozen": self.frozen, "network_params": self.network_params._asdict(),
+                        "model_state": self.model.state_dict()}}
+
+    def overlay_params(self, new_params, device=None):
+        if not new_params:
+            return self
+        runtime = new_params.pop("runtime")
+        assert not new_params
+        runtime["frozen"] = True
+        return type(self)(self.model, self.NetworkParams(self.network_params.model, runtime), device or self.device, frozen=True)
+
+    def overlay_model(self, new_model, device=None):
+        return type(self)(new_model, self.network_params, device or self.device, frozen=True)
 
     def __repr__(self):
         params = "\n" + "".join("    %s: %s,\n" % kv for kv in self.network_params._asdict().items())
@@ -176,8 +220,8 @@ class SingleNetwork(Network):
 
 
 class SequentialNetwork(Network):
-    """Two frozen-or-not networks chained: ``image = first(image); image = last(image)``; the last network's wrappers
-    are hoisted to the container (mdir/learning/network.py:639-677)."""
+    """Two networks in a row (``sequence="first,last"``): ``last(first(image))``.  By default the last network's wrappers move to
+    the container, so that e.g. multi-scale aggregation wraps the whole chain and not just the embedder."""
 
     NetworkParams = namedtuple("NetworkParams", ["runtime"])
 
@@ -185,68 +229,61 @@ class SequentialNetwork(Network):
         assert len(networks) == 2
         self.networks = networks
         self.network_order = list(sequence)
-        first_net = networks[sequence[0]]
-        self.last_net = networks[sequence[1]]
-        self.stage = None
-        self.frozen = frozen
-        self.model = self.last_net.model
+        first, last = networks[sequence[0]], networks[sequence[1]]
+        assert first.meta["out_channels"] == last.meta["in_channels"]
+        self.last_net = last
+        self.model = last.model
         self.device = device
+        self.frozen = frozen
+        self.meta = {"in_channels": first.meta["in_channels"], "out_channels": last.meta["out_channels"]}
+        data = first.network_params.runtime["data"]
         if rearrange_wrappers:
-            self.wrappers = self.last_net.wrappers
-            self.last_net.wrappers = self.initialize_wrappers("", device)
-            self.network_params = self.NetworkParams({"wrappers": self.last_net.network_params.runtime["wrappers"],
-                                                      "data": first_net.network_params.runtime["data"]})
+            self.wrappers, last.wrappers = last.wrappers, _wrapper_chains("", device)
+            self.network_params = self.NetworkParams({"wrappers": last.network_params.runtime["wrappers"], "data": data})
         else:
-            self.wrappers = self.initialize_wrappers("", device)
-            self.network_params = self.NetworkParams({"wrappers": "", "data": first_net.network_params.runtime["data"]})
-        assert first_net.meta["out_channels"] == self.last_net.meta["in_channels"]
-        self.meta = {"in_channels": first_net.meta["in_channels"], "out_channels": self.last_net.meta["out_channels"]}
+            self.wrappers = _wrapper_chains("", device)
+            self.network_params = self.NetworkParams({"wrappers": "", "data": data})
         if frozen:
             self.eval()
 
-    def train(self):
+    def _members(self):
+        return tuple(self.networks.values())
+
+    def train(self):                        # member networks apply their own frozen flags
         for n in self.networks.values():
             n.train()
-        self.stage = Network.TRAIN
-        return self
-
-    def eval(self):
-        for n in self.networks.values():
-            n.eval()
-        self.stage = Network.EVAL
+        self.stage = TRAIN
         return self
 
     def forward(self, image):
         return self.wrappers[self.stage](image, self.forward_batch, outputmodel=self.model)
 
+    def _chain(self, image):
+        for name in self.network_order:
+            image = self.networks[name](image)
+        return image
+
     def forward_batch(self, images):
         if images is None:
             return None
         if isinstance(images, list):
-            return [self._forward_all(x) for x in images]
-        return self._forward_all(images)
-
-    def _forward_all(self, image):
-        for net in self.network_order:
-            image = self.networks[net](image)
-        return image
+            return [self._chain(x) for x in images]
+        return self._chain(images)
 
     @classmethod
     def initialize(cls, params, device):
         sequence = params.pop("sequence").split(",")
-        rearrange = params.pop("rearrange_wrappers") if "rearrange_wrappers" in params else True
+        rearrange = params.pop("rearrange_wrappers", True)
         networks = {name: initialize_network(params.pop(name), device) for name in sequence}
         assert not params, params.keys()
         return cls(networks, sequence, device=device, frozen=False, rearrange_wrappers=rearrange)
 
 
 class CirSequentialNetwork(SequentialNetwork):
-    """Does not split a list of images into single forwards (mdir/learning/network.py:747-753)."""
+    """The retrieval flavour hands a list of images to the chain as it is (the embedder's tuple-batch wrapper deals with it)."""
 
     def forward_batch(self, images):
-        if images is None:
-            return None
-        return self._forward_all(images)
+        return None if images is None else self._chain(images)
 
 
 NETWORKS = {
@@ -257,7 +294,8 @@ NETWORKS = {
 
 
 def initialize_network(params, device, state=None, runtime=None):
-    network_cls = NETWORKS[params.pop("type") if params else state["net"]["type"]]
+    kind = params.pop("type") if params else state["net"]["type"]
+    cls = NETWORKS[kind]
     if state:
-        return network_cls.initialize_from_state(state, device, params, runtime)
-    return network_cls.initialize(params, device)
+        return cls.initialize_from_state(state, device, params, runtime)
+    return cls.initialize(params, device)

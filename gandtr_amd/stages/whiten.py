@@ -19,8 +19,8 @@ def _device():
 
 def whiten(params, data):
     """Apply pre-computed whitening (mdir/stages/whiten.py:10-27; whitenapply, cirtorch/utils/whiten.py:4-12).  The reference
-    multiplies in float64 on the host (numpy promotes against the float64 P); ``gdt_whiten`` works in float32 like the ``cirwhiten``
-    wrapper of the inference path (wrapper.py:320-322): unit-norm outputs agree to ~1e-6."""
+    multiplies in float64 on the host (numpy promotes against the float64 P): so does the device path here (``gdt_whiten_f64``);
+    the float32 ``gdt_whiten`` is the arithmetic of the ``cirwhiten`` wrapper of the inference path (wrapper.py:320-322)."""
     dimensions = params.pop("dimensions", None) or None
     assert not params, params.keys()
     whitening, names, values = data
@@ -29,10 +29,10 @@ def whiten(params, data):
         return {"status": "No whitening applied"}, names, values
     dev = _device()
     time0 = time.time()
-    v = torch.as_tensor(np.asarray(values), dtype=torch.float32, device=dev)                       # N x D
-    P = torch.as_tensor(np.asarray(whitening["P"]), dtype=torch.float32, device=dev)
-    m = torch.as_tensor(np.asarray(whitening["m"]), dtype=torch.float32, device=dev).reshape(-1)
-    whitened = engine.whiten(v, P, m, dimensions).cpu().numpy()                                    # N x dims
+    v = torch.as_tensor(np.asarray(values), dtype=torch.float64, device=dev)                       # N x D
+    P = torch.as_tensor(np.asarray(whitening["P"]), dtype=torch.float64, device=dev)
+    m = torch.as_tensor(np.asarray(whitening["m"]), dtype=torch.float64, device=dev).reshape(-1)
+    whitened = engine.whiten(v, P, m, dimensions, float64=True).cpu().numpy()                      # N x dims, float64 like the reference
     return {"timings": {"whitening_apply": round(time.time() - time0, 2)}}, names, whitened
 
 

@@ -35,6 +35,20 @@ def fs_open(path):
     return open(path, "rb")
 
 
+class _ArrayUnpickler(pickle.Unpickler):
+    """The whitening files are ``{"P": ndarray, "m": ndarray}`` (mdir/stages/whiten.py:75): plain containers and numpy arrays only.
+    Anything else in the stream (it may have come over plain http, hub/model.py BASE_URL) is refused instead of executed."""
+
+    _ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy.core.numeric", "_frombuffer"),
+                ("numpy._core.numeric", "_frombuffer"), ("collections", "OrderedDict")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to unpickle %s.%s (only containers and numpy arrays are accepted)" % (module, name))
+
+
 def fs_load_pickle(path):
     with fs_open(path) as handle:
-        return pickle.load(handle)
+        return _ArrayUnpickler(handle).load()

@@ -28,6 +28,7 @@ extern "C" {
 #define GDT_ERR_INVALID 1   /* bad argument / unsupported shape   */
 #define GDT_ERR_HIP 2       /* a HIP runtime call failed          */
 #define GDT_ERR_WORKSPACE 3 /* workspace too small                */
+#define GDT_ERR_NOT_CONVERGED 4 /* an iterative solver hit its cap */
 
 const char* gdt_last_error(void);
 /* library self-description: "gandtr_hip <version> gfx950" */
@@ -138,6 +139,16 @@ int gdt_ms_aggregate(const float* x, float* y, int scales, int n, int d, float m
 /* CirtorchWhiten.postprocess (wrapper.py:320-322), batched: v [N][D], P [D][D] row-major, m [D] -> out [N][dims],
  * out = P[:dims] (v - m) / (||.||_2 + 1e-6).  tmp: [N][dims] scratch. */
 int gdt_whiten(const float* P, const float* m, const float* v, float* tmp, float* out, int n, int d, int dims, void* stream);
+/* the same in float64: the arithmetic of the reference's `whiten` STAGE (mdir/stages/whiten.py:20-23 -> whitenapply,
+ * mdir/external/cirtorch/utils/whiten.py:4-12: numpy promotes against the float64 P) */
+int gdt_whiten_f64(const double* P, const double* m, const double* v, double* tmp, double* out, int n, int d, int dims, void* stream);
+
+/* LF.gem + LF.l2n on an fp32 NCHW feature map (cirtorch layers/functional.py:21-22, :130-131; the tail of
+ * ImageRetrievalNet.forward, networks/imageretrievalnet.py:113):
+ *   pooled[n][c] = (mean_{hw} max(x, eps_gem)^p)^(1/p);   out[n][:] = pooled[n][:] / (||pooled[n]||_2 + eps_l2)
+ * fmap [n][d][h][w]; pooled, out: [n][d] (the memory the reference's D x N view aliases).  Stand-alone form of the GeM / L2N ops
+ * that gdt_net_gem_l2n fuses behind a trunk (any d; SURVEY.md section 8b lists it in the minimum C ABI). */
+int gdt_gem_l2n(const float* fmap, int n, int d, int h, int w, float p, float eps_gem, float eps_l2, float* pooled, float* out, void* stream);
 
 /* x / (||x||_2 + eps) over rows of a [N][D] matrix (cirtorch layers/functional.py:130-131) */
 int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream);
@@ -194,7 +205,8 @@ int gdt_ingest_resize_u8(const unsigned char* src, int h, int w, int c, int fx, 
  * the matching query / positive pairs.  All arithmetic in float64.  Outputs (device): m [d], P [d][d] row-major, eig [d] (may be
  * NULL) = eigenvalues in decreasing order.  info (host, may be NULL): info[0] = diagonal-jitter steps of the Cholesky
  * (whiten.py:55-70), info[1] = Jacobi sweeps.  The call synchronises the stream (convergence checks).  Rows of P are defined up
- * to sign (eigenvectors).
+ * to sign (eigenvectors).  Returns GDT_ERR_NOT_CONVERGED (4) when the eigensolver stops at its sweep cap (60 one-sided / 40 two-sided
+ * sweeps) without meeting its convergence test; the outputs are then best-effort values.
  * ------------------------------------------------------------------------------------------------------------------ */
 int gdt_whiten_learn_workspace_bytes(int n_vec, int d, int n_pairs, size_t* bytes);
 int gdt_whiten_learn(const float* x, const int* qidx, const int* pidx, int n_vec, int d, int n_pairs, double* m_out, double* p_out,

@@ -34,6 +34,7 @@ _ALIASES = {
     "mdir.stages": "gandtr_amd.stages",
     "mdir.stages.infer": "gandtr_amd.stages.infer",
     "mdir.stages.whiten": "gandtr_amd.stages.whiten",
+    "mdir.stages.validate": "gandtr_amd.stages.validate",
     "mdir.tools": "gandtr_amd.tools",
     "mdir.tools.tensors": "gandtr_amd.tools.tensors",
     "mdir.tools.utils": "gandtr_amd.tools.utils",

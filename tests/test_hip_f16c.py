@@ -1,0 +1,194 @@
+"""GPU parity of the "f16c" precision mode (fp16 MFMA product + block-scaled fp4 x fp6 correction product, conv3x3_halo_c.hip) layer by
+layer, of the stand-alone GeM / L2N entry point against the reference's golden vectors, and of the validate-shaped caller.
+
+A compensated conv is held to 2e-4 of an fp64 evaluation of the same layer on the same fp32 inputs -- single-pass fp16 measures
+5e-4 on these layers, so a correction product that silently did nothing (wrong operand layout, wrong block scale) fails here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gandtr_amd import engine
+from gandtr_amd.engine import HipNet
+from gandtr_amd.tools import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _g(seed, name, shape, std=1.0):
+    return synth._normal(seed, name, shape, std)
+
+
+@pytest.mark.parametrize("norm,res,reflect", [(False, False, True), (False, False, False), (True, False, True), (True, True, True)])
+def test_halo_c_conv3x3(cuda_device, norm, res, reflect):
+    """3x3 / stride 1 conv 256 -> 256 on 8 x 64 x 64 (128 patches: the persistent compensated kernel runs): plain, with the producer's
+    InstanceNorm + ReLU folded into the staging (+ write-back: the normalised tensor is also an output), and with the ResnetBlock form
+    x + IN(conv) folded in.  The statistics of ITS output feed a following InstanceNorm."""
+    cin = cout = 256
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+    t = t0
+    if norm:
+        r = net.conv(t0, _g(0, "w1", (cin, cin, 1, 1), 0.06)) if res else -1
+        t = net.instance_norm(t0, relu=not res, residual=r)
+    wt, bias = _g(0, "w", (cout, cin, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
+    out = net.conv(t, wt, bias, pad=1, reflect=reflect)
+    o2 = net.instance_norm(out, relu=True)
+    taps = [net.output_nchw(out), net.output_nchw(o2)] + ([net.output_nchw(t)] if norm else [])
+    net.finalize()
+    x = synth.synth_input(1, (8, 3, 64, 64))
+    outs = net.forward(x.to(cuda_device))
+    a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
+    a = a0
+    if norm:
+        a = F.instance_norm(a0, eps=1e-5)
+        a = a + F.conv2d(a0, _g(0, "w1", (cin, cin, 1, 1), 0.06).double()) if res else F.relu(a)
+    ai = F.pad(a, (1,) * 4, mode="reflect") if reflect else a
+    ref = F.conv2d(ai, wt.double(), bias.double(), padding=0 if reflect else 1)
+    assert _rel(outs[taps[0]].double().cpu(), ref) < 2e-4
+    assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 3e-4
+    if norm:
+        assert _rel(outs[taps[2]].double().cpu(), a) < 1e-5          # the write-back of the folded normalisation is plain fp32
+
+
+@pytest.mark.parametrize("cin,cout,norm,res", [(256, 128, False, False), (256, 128, True, True), (128, 64, True, False)])
+def test_halo_c_transposed(cuda_device, cin, cout, norm, res):
+    """ConvTranspose2d(k3, s2, p1, op1) on the compensated kernel's transposed form (four input shifts, sub-pixel scatter), with the
+    producer's InstanceNorm (+ReLU | + residual) folded in and the statistics of its output taken in the epilogue"""
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+    t = t0
+    if norm:
+        r = net.conv(t0, _g(0, "w1", (cin, cin, 1, 1), 0.06)) if res else -1
+        t = net.instance_norm(t0, relu=not res, residual=r)
+    wt, bias = _g(0, "w", (cin, cout, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
+    out = net.conv(t, wt, bias, stride=2, pad=1, transposed=True)
+    o2 = net.instance_norm(out, relu=True)
+    taps = [net.output_nchw(out), net.output_nchw(o2)]
+    net.finalize()
+    x = synth.synth_input(1, (8, 3, 64, 64))
+    outs = net.forward(x.to(cuda_device))
+    a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
+    a = a0
+    if norm:
+        a = F.instance_norm(a0, eps=1e-5)
+        a = a + F.conv2d(a0, _g(0, "w1", (cin, cin, 1, 1), 0.06).double()) if res else F.relu(a)
+    ref = F.conv_transpose2d(a, wt.double(), bias.double(), stride=2, padding=1, output_padding=1)
+    assert outs[taps[0]].shape == ref.shape
+    assert _rel(outs[taps[0]].double().cpu(), ref) < 3e-4
+    assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 4e-4
+
+
+def test_f16c_small_geometries_fall_back_to_the_exact_split(cuda_device):
+    """below the patch kernels' tile threshold / channel counts the mode runs the generic f16x3 kernels: same answers as f16x3"""
+    sd = synth.generator_state(0, "instance", ngf=16, n_blocks=3)
+    x = synth.synth_input(11, (3, 3, 36, 132), 1.0).to(cuda_device)
+    a = engine.build_generator(sd, cuda_device, pre_tanh=True, precision="f16c")
+    b = engine.build_generator(sd, cuda_device, pre_tanh=True, precision="f16x3")
+    assert torch.equal(a.forward(x)[a.out_slot], b.forward(x)[b.out_slot])
+
+
+def test_gem_l2n_golden(cuda_device):
+    """stand-alone gdt_gem_l2n against the outputs of the reference's own LF.gem / LF.l2n (tests/golden/gem_l2n.npz, made by
+    tests/golden/make_golden.py): p in {3, 2.37}, inputs with exact zeros and negatives (the clamp path, functional.py:22)"""
+    g = np.load(os.path.join(G, "gem_l2n.npz"))
+    x = torch.from_numpy(g["x"]).to(cuda_device)
+    assert float((x == 0).float().mean()) > 0 or float((x < 0).float().mean()) > 0
+    for p in ("3.0", "2.37"):
+        pooled, normed = engine.gem_l2n(x, float(p))
+        assert pooled.shape == g["gem_p" + p].shape
+        assert float((pooled.cpu() - torch.from_numpy(g["gem_p" + p])).abs().max()) < 1e-6
+        assert float((normed.cpu() - torch.from_numpy(g["l2n_p" + p])).abs().max()) < 1e-6
+    # a feature map of the embedder's real size: against torch
+    f = torch.rand(2, 2048, 32, 32, device=cuda_device) - 0.2
+    pooled, normed = engine.gem_l2n(f, 3.0)
+    ref = F.avg_pool2d(f.clamp(min=1e-6).pow(3.0), (32, 32)).pow(1.0 / 3.0)
+    assert float((pooled - ref).abs().max()) < 1e-5
+    assert float((normed - ref / (ref.norm(dim=1, keepdim=True) + 1e-6)).abs().max()) < 1e-6
+
+
+def test_validate_stage_on_gpu(cuda_device):
+    """mdir.stages.validate.validate on the device: batch-1 descriptor extraction (HIP embedder) and device-side ranking agree with
+    the reference's two numpy lines on the same descriptors (cirscore.py:71-73)"""
+    import copy
+    from gandtr_amd.stages.validate import validate, extract_vectors
+    import gandtr_amd.learning as L
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False, "path": None,
+           "runtime": {"wrappers": "cirfaketuplebatch",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    db = [synth.synth_input(40 + i, (3, 96, 128 - 16 * (i % 3))) for i in range(12)]
+    qs = [db[7] + 0.01 * synth.synth_input(50, db[7].shape), db[2]]
+    meta, ranks, scores = validate({"network": copy.deepcopy(emb), "validation": {}, "data": {}}, (db, qs))
+    assert ranks.shape == (12, 2) and ranks[0, 0] == 7 and ranks[0, 1] == 2
+    net = L.load_network(copy.deepcopy(emb), cuda_device).eval()
+    vecs = extract_vectors(net, db, cuda_device)
+    assert vecs.is_cuda and vecs.shape == (512, 12)
+    v, q = vecs.cpu().numpy(), extract_vectors(net, qs, cuda_device).cpu().numpy()
+    ref_scores = np.dot(v.T, q)
+    assert np.abs(scores - ref_scores).max() < 1e-5
+    assert np.array_equal(ranks, np.argsort(-ref_scores, axis=0)) or np.abs(np.take_along_axis(ref_scores, ranks, 0) -
+                                                                              np.sort(ref_scores, axis=0)[::-1]).max() < 1e-6
+
+
+def test_fused_statistics_with_an_odd_number_of_128_row_records(cuda_device):
+    """InstanceNorm statistics from a conv epilogue whose 256-row tiles do not divide the layer (N*OH*OW = 128 * odd): the last tile
+    owns ONE record, not two (the slab holds M / 128 records; conv_epilogue.h).  The normalised output must be right and the tensor
+    allocated right behind the slab must stay intact."""
+    net = HipNet(cuda_device, "f16")
+    t = net.input(3)
+    w = _g(0, "w", (64, 3, 7, 7), 0.1)
+    raw = net.conv(t, w, None, pad=3, reflect=True)
+    out = net.instance_norm(raw, relu=True)
+    slot = net.output_nchw(out)
+    net.finalize()
+    x = synth.synth_input(5, (1, 3, 384, 683), 1.0)               # M = 262272 = 128 * 2049; width not a multiple of 32: generic kernel
+    got = net.forward(x.to(cuda_device))[slot].cpu()
+    ref = F.relu(F.instance_norm(F.conv2d(F.pad(x, (3,) * 4, mode="reflect"), w.half().float()), eps=1e-5))
+    assert got.shape == ref.shape and _rel(got, ref) < 4e-3
+
+
+def test_config5_full_size_chain(cuda_device):
+    """BASELINE config 5 at its full per-rank size: cyclegan on 128 x 3 x 256 x 256 -> meanstd_post -> GeM-ResNet-101 descriptors
+    through the container API; two of the 128 images against the CPU oracle (north_star gates), all columns unit-norm"""
+    from gandtr_amd.learning import network as N
+    from oracle import gandtr_oracle as O
+    gen = {"type": "SingleNetwork",
+           "model": {"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "n_blocks": 9,
+                     "norm_layer": "instance", "no_antialias": True, "no_antialias_up": True},
+           "initialize": False,
+           "runtime": {"wrappers": "meanstd_post:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.485,0.456,0.406],[0.229,0.224,0.225]]",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "resnet101", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False,
+           "runtime": {"wrappers": "cirfaketuplebatch",
+                       "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen, "embed": emb}, cuda_device).eval()
+    gsd, esd = synth.generator_state(0, "instance", gain=0.02), synth.resnet101_state(0, p=3.0)
+    chain.networks["augment"].model.load_state_dict(gsd)
+    chain.networks["embed"].model.load_state_dict(esd)
+    x = synth.synth_input(9, (128, 3, 256, 256), 1.0)
+    with torch.no_grad():
+        d = chain(x.to(cuda_device))
+    assert d.shape == (2048, 128)
+    assert torch.allclose(d.norm(dim=0), torch.ones(128, device=d.device), atol=1e-5)
+    for i in (3, 127):
+        y = O.resnet_generator(x[i:i + 1], gsd, "instance", 9)
+        y = (y * 0.5 + 0.5 - torch.tensor([0.485, 0.456, 0.406])[:, None, None]) / torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+        ref = O.image_retrieval_forward(y, esd, "resnet101")[:, 0]
+        got = d[:, i].cpu()
+        assert float(torch.nn.functional.cosine_similarity(got, ref, dim=0)) >= 0.9999
+        assert float((got - ref).abs().max()) <= 1e-3

@@ -101,15 +101,22 @@ def test_embedder_hub_paths_on_gpu(cuda_device, arch, p, tmp_path):
         assert float(torch.nn.functional.cosine_similarity(both.cpu().t(), refh, dim=1).min()) > 0.9999
 
 
-def test_hed_with_wrappers_on_gpu(cuda_device):
+def test_hed_with_wrappers_on_gpu(cuda_device, monkeypatch):
     g = load("hed")
     params = {"type": "SingleNetwork", "model": {"architecture": "hed_interpolation"}, "initialize": False,
               "runtime": {"wrappers": "rgb2bgr_pre, meanstd_pre:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.40787054,0.45752458,0.48109378],[1,1,1]]"}}
     net = N.initialize_network(params, cuda_device).eval()
     net.model.load_state_dict(synth.hed_state(0))
+    # on a HIP device both wrappers are folded into the HED net's input-pack kernel (no torch op on the data path): their own
+    # preprocess must not run
+    for w in net.wrappers["eval"].wrappers:
+        monkeypatch.setattr(w, "preprocess", lambda *a, **k: (_ for _ in ()).throw(AssertionError("wrapper ran as a torch op")))
     with torch.no_grad():
         out = net(synth.synth_input(8, (2, 3, 64, 96), 1.0).to(cuda_device))   # the generator output lives on the device
     assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
+    keys = [k for k in net.model._hip_cache if isinstance(k, tuple) and k[0] == "hed"]
+    assert keys and keys[0][3] is not None and keys[0][3][0] == (2, 1, 0)
+    assert net.model.input_transform is None                                    # restored after the call
 
 
 def test_chain_config5_on_gpu(cuda_device):
