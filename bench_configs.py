@@ -68,10 +68,22 @@ def main():
                                                             "[[0.40787054,0.45752458,0.48109378],[1,1,1]]"}}, dev).eval()
         hed.model.load_state_dict(synth.hed_state(0))
         x = synth.synth_input(3, (64, 3, 256, 256), 1.0).to(dev)
+        # the generator's default precision is "f16c" (north_star's 1e-3); the single-pass fp16 numbers are the opt-in fast mode
         r, ms = rate(lambda: hed(gen(x)), 64)
         rg, msg = rate(lambda: gen(x), 64)
+        y = gen(x)
+        rh, msh = rate(lambda: hed(y), 64)
+        gen.model.hip_precision = "f16"
+        rf, msf = rate(lambda: hed(gen(x)), 64)
+        rgf, _ = rate(lambda: gen(x), 64)
+        gen.model.hip_precision = None
         out["c2_hedngan_plus_hed_64x256"] = {"images_per_s": r, "ms_per_batch": ms, "generator_only_images_per_s": rg,
-                                             "tflops": round(r * 139.2 / 1e3, 1)}
+                                             "hed_leg_ms": msh, "tflops": round(r * 139.2 / 1e3, 1),
+                                             "fast_mode_f16": {"images_per_s": rf, "ms_per_batch": msf, "generator_only_images_per_s": rgf}}
+        # regression guard (round 1 saw this leg at 4.2 -> 6.5 ms with no kernel change; root cause in DESIGN.md section 6): the HED leg
+        # (40.1 GFLOP / image, wrappers folded into its input pack) must stay under 4.5 ms per 64-image batch
+        out["c2_hedngan_plus_hed_64x256"]["hed_leg_within_4p5_ms"] = bool(msh < 4.5)
+        del y
         del gen, hed, x
         torch.cuda.empty_cache()
 
@@ -117,7 +129,11 @@ def main():
         chain.networks["embed"].model.load_state_dict(synth.resnet101_state(0))
         x = synth.synth_input(5, (128, 3, 256, 256), 1.0).to(dev)
         r, ms = rate(lambda: chain(x), 128)
-        out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1)}
+        chain.networks["augment"].model.hip_precision = "f16"
+        rf, msf = rate(lambda: chain(x), 128)
+        chain.networks["augment"].model.hip_precision = None
+        out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1),
+                                                "fast_mode_f16_generator": {"images_per_s": rf, "ms_per_batch": msf}}
         # the same chain with the reference's CLAHE step between generator and embedder (finetune.yml:13: wrappers
         # meanstd_post, clahepost -- post-processing runs in reverse order: CLAHE first, then the ImageNet mean / std)
         gen_c["runtime"]["wrappers"] += ",clahepost:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:1.0"
