@@ -43,7 +43,7 @@ constexpr int Q_BYTES = HALO_ROWS_PAD * QROWB;             // 20992
 constexpr int STAGE_BYTES = A_BYTES + Q_BYTES;             // 62976
 constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
 constexpr int BM = PH * 16;
-constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES;
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES + 4 * 4096;        // + one 4 KB epilogue patch per wave
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -91,6 +91,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     int vb = blockIdx.x;
     TileAt cur = tile_at(vb);
     if (!cur.valid) return;
+    // Stagger: every workgroup runs the same number of equally long tiles, so without it all 256 CUs reach their epilogue in the
+    // same microsecond, the chip's whole output (64 MB per round at batch 64) leaves in one burst and every wave then sits behind its
+    // own stores (in-order vmcnt) for the ~20 us the burst takes to drain.  Four phase groups, d.stagger_us apart, spread it.
+    if (d.stagger_us > 0) {
+        const int grp = (blockIdx.x >> 3) & 3;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)grp * d.stagger_us * 2000;      // s_memtime counts shader cycles (~2 GHz under load)
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- halo loader: through registers, branch-free (see conv3x3_halo_rb.hip for why)
     const int lrow = tid >> 3;
@@ -385,96 +394,76 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
-        // ------------------------------------------------------------ epilogue, straight from the accumulators (wave-private, no
-        // LDS): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3, the output channels 8g + 4fh .. +3 of
-        // column block j: one 16-byte fp32 store each.
+        // ------------------------------------------------------------ epilogue, wave-private (no workgroup barrier).  MFMA operands
+        // are swapped (D = W * A^T): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3, the output channels
+        // 8g + 4fh .. +3 of column block j.  Stored like that, one store instruction touches 32 different 128-byte lines with 32 bytes
+        // each, and the address unit -- not HBM -- sets the pace (measured: 18 % of the kernel).  So every 32 x 32 block goes through a
+        // 4 KB patch of the wave's own (XOR-swizzled, conflict-free both ways): written as it sits in the registers, read back with
+        // 8 lanes per pixel, i.e. whole 128-byte lines per store instruction.  Statistics: a lane then owns 4 channels of 4 pixels per
+        // block; the 8 pixel lanes are merged by a fixed butterfly.
         if (!(d.dbg & 4)) {
             float* __restrict__ outp = (float*)d.out;
             const float* __restrict__ resp = (const float*)d.res;
-            int fr_e = fr, fh_e = fh;
-            asm volatile("" : "+v"(fr_e), "+v"(fh_e));
-            unsigned offs[TM]; unsigned okm = 0;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = wm * WTM + i * 32 + fr_e;
-                const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
-                const bool ok = (y < d.H) & (x < d.W);
-                offs[i] = ok ? (unsigned)((cur.n * d.H + y) * d.W + x) : 0u;
-                okm |= (ok ? 1u : 0u) << i;
-            }
+            float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * 1024;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));             // (opaque copy: keeps the epilogue's addresses out of the loop's invariant set)
+            const int fr_e = lane_e & 31, fh_e = lane_e >> 5, pl = lane_e >> 3, q = lane_e & 7;
             const bool relu_now = d.relu != 0;
-            float st[32];                                  // [which][g][c]: sum / sum of squares over this lane's pixels (CT: both phases)
+            const int wswz = ((fr_e >> 1) & 7) << 2;
+            float st1[4], st2[4];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int colb = cur.tile_n * BN + wn * WTN + j * 32 + 4 * fh_e;       // + 8g: this lane's channel quads
+                const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;         // this lane's 4 channels after the transpose
+                const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                int ct_ph = 0, ct_co = 0;
+                if (CT) gdt_ctf_column(colq, d.phase_cout, ct_ph, ct_co);
                 if (!CT || (j & 1) == 0) {
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) st[e] = 0.f;
+                    for (int e = 0; e < 4; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
                 }
-                float4 bv[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bv[g] = d.bias ? *(const float4*)(d.bias + colb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const bool ok = (okm >> i) & 1u;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x16& a = acc[i][j];
-                        float4 v = make_float4(a[4 * g] + bv[g].x, a[4 * g + 1] + bv[g].y, a[4 * g + 2] + bv[g].z, a[4 * g + 3] + bv[g].w);
-                        const bool okc = ok & (colb + 8 * g < d.Cout);
-                        if (CT) {
-                            // GEMM column -> (sub-pixel phase, output channel): quads never straddle a 32-column block
-                            int ph, co;
-                            gdt_ctf_column(colb + 8 * g, d.phase_cout, ph, co);
-                            const int m = wm * WTM + i * 32 + fr_e;
-                            const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
-                            if (okc) {
-                                if (d.stats) {
-                                    st[g * 4 + 0] += v.x; st[g * 4 + 1] += v.y; st[g * 4 + 2] += v.z; st[g * 4 + 3] += v.w;
-                                    st[16 + g * 4 + 0] += v.x * v.x; st[16 + g * 4 + 1] += v.y * v.y; st[16 + g * 4 + 2] += v.z * v.z; st[16 + g * 4 + 3] += v.w * v.w;
-                                }
-                                if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                                *(float4*)(outp + ((size_t)((cur.n * d.OH + 2 * y + (ph >> 1)) * d.OW + 2 * x + (ph & 1)) * d.phase_cout + co)) = v;
-                            }
-                            continue;
-                        }
-                        if (okc) {
+                        *(float4*)(patch + fr_e * 32 + ((8 * g + 4 * fh_e) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = 8 * k + pl;
+                        float4 v = *(const float4*)(patch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        const int m = wm * WTM + i * 32 + row;
+                        const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
+                        if ((y < d.H) & (x < d.W) & (colq < d.Cout)) {
                             if (d.stats) {
-                                st[g * 4 + 0] += v.x; st[g * 4 + 1] += v.y; st[g * 4 + 2] += v.z; st[g * 4 + 3] += v.w;
-                                st[16 + g * 4 + 0] += v.x * v.x; st[16 + g * 4 + 1] += v.y * v.y; st[16 + g * 4 + 2] += v.z * v.z; st[16 + g * 4 + 3] += v.w * v.w;
+                                st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
+                                st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
                             }
-                            const size_t o = (size_t)offs[i] * d.Cout + colb + 8 * g;
-                            if (resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                            size_t o;
+                            if (CT) o = (size_t)((cur.n * d.OH + 2 * y + (ct_ph >> 1)) * d.OW + 2 * x + (ct_ph & 1)) * d.phase_cout + ct_co;
+                            else o = (size_t)((cur.n * d.H + y) * d.W + x) * d.Cout + colq;
+                            if (!CT && resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                             if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                             *(float4*)(outp + o) = v;
                         }
                     }
                 }
                 if (d.stats && (!CT || (j & 1) == 1)) {
-                    // halving butterfly over the 32 pixel lanes (fr): 32 values -> 1 per lane.  After the masks 16, 8, 4, 2, 1 lane
-                    // fr holds value index k = fr: which = fr >> 4, g = (fr >> 2) & 3, c = fr & 3.
-                    float v16[16], v8[8], v4[4], v2[2], v1;
-                    const bool b4 = (fr_e >> 4) & 1, b3 = (fr_e >> 3) & 1, b2 = (fr_e >> 2) & 1, b1 = (fr_e >> 1) & 1, b0 = fr_e & 1;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) { const float snd = b4 ? st[k] : st[k + 16]; v16[k] = (b4 ? st[k + 16] : st[k]) + __shfl_xor(snd, 16); }
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const float snd = b3 ? v16[k] : v16[k + 8]; v8[k] = (b3 ? v16[k + 8] : v16[k]) + __shfl_xor(snd, 8); }
+                        for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
+                    if (pl == 0 && colq < d.Cout) {
+                        float* dst;
+                        if (!CT) dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + colq;
+                        else {              // one record set per phase pair (the wave's two blocks of a 64-column slice), the finalize kernel sums the sets
+                            const int pair = ((colq >> 6) / (d.phase_cout >> 5)) & 1;
+                            dst = d.stats + ((long)(pair * (ntm * WGM) + cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
+                        }
+                        const int cstride = CT ? d.phase_cout : d.Cout;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { const float snd = b2 ? v8[k] : v8[k + 4]; v4[k] = (b2 ? v8[k + 4] : v8[k]) + __shfl_xor(snd, 4); }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) { const float snd = b1 ? v4[k] : v4[k + 2]; v2[k] = (b1 ? v4[k + 2] : v4[k]) + __shfl_xor(snd, 2); }
-                    { const float snd = b0 ? v2[0] : v2[1]; v1 = (b0 ? v2[1] : v2[0]) + __shfl_xor(snd, 1); }
-                    const int which = fr_e >> 4, g = (fr_e >> 2) & 3, cc = fr_e & 3;
-                    const int col = cur.tile_n * BN + wn * WTN + j * 32 + 8 * g + 4 * fh_e + cc;
-                    if (!CT) {
-                        if (col < d.Cout) d.stats[((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2 + which) * d.Cout + col] = v1;
-                    } else {
-                        // the wave's two column blocks are two sub-pixel phases of the same 32 output channels (summed in st above);
-                        // one record set per phase pair, the finalize kernel sums the two sets
-                        int ph, co;
-                        gdt_ctf_column(col, d.phase_cout, ph, co);
-                        const int pair = ((col >> 6) / (d.phase_cout >> 5)) & 1;
-                        d.stats[((long)(pair * (ntm * WGM) + cur.tile_m * WGM + wm) * 2 + which) * d.phase_cout + co] = v1;
+                        for (int e = 0; e < 4; ++e) { dst[e] = st1[e]; dst[cstride + e] = st2[e]; }
                     }
                 }
             }
@@ -541,6 +530,8 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
+    static const int stagger = [] { const char* e = getenv("GDT_C_STAGGER_US"); return e ? atoi(e) : 0; }();
+    d.stagger_us = stagger;
     if (!d.in_norm) return launch_c<0>(d, stream);
     if (d.in_res) {
         if (d.in_out) return launch_c<7>(d, stream);
