@@ -53,13 +53,19 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 
 // MODE bits: 1 = the producer's InstanceNorm (+ReLU) is applied while staging; 2 = ... plus a residual; 4 = the transformed
 // tensor is written back.  CT: transposed form (see conv3x3_halo_rb.hip).
-template <int BN, int WGM, int WGN, int MODE, bool CT = false>
+// FORM 0: 3x3 / stride 1.  FORM 1 (CT): ConvTranspose2d(k3,s2,p1,op1), see conv3x3_halo_rb.hip.  FORM 2 (S2): Conv2d(k3, s2, p1, zero
+// padding) as a 2x2-shift convolution over the space-to-depth view of its input (x[2R+py][2C+px][c] = channel (2py+px)*Cin + c of
+// S2D pixel (R, C)): out[y][x] = sum over shifts (dy, dx) in {-1, 0}^2 and the 4*Cin virtual channels, with the (shift, parity)
+// pairs that do not occur as zero weight blocks that are skipped (9 of 16 remain).  The S2D tensor is never materialised: the halo
+// loader maps (S2D pixel, virtual channel) to the NHWC address.  16x16 OUTPUT patch, 17x17 S2D halo, the 4 shifts as taps.
+template <int BN, int WGM, int WGN, int MODE, int FORM = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const ConvLaunch d, const int vblocks) {
+    constexpr bool CT = FORM == 1, S2 = FORM == 2, SHIFT = FORM != 0;
     constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
-    constexpr int HW_ = CT ? 17 : HALO_W;
+    constexpr int HW_ = SHIFT ? 17 : HALO_W;
     constexpr int HROWS = HW_ * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;
-    constexpr int NTAP = CT ? 4 : 9;
+    constexpr int NTAP = SHIFT ? 4 : 9;
     constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
     // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
     // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
@@ -77,7 +83,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     const float* __restrict__ resf = (const float*)d.in_res;
     float* __restrict__ wbf = (float*)d.in_out;
 
-    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + PH - 1) / PH;
+    const int GH = S2 ? d.OH : d.H, GW = S2 ? d.OW : d.W;              // the grid the 16x16 patches tile (S2: the output)
+    const int tiles_x = (GW + 15) >> 4, tiles_y = (GH + PH - 1) / PH;
     const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
     auto tile_at = [&](int vb) -> TileAt {
         TileAt t;
@@ -110,15 +117,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         int lr = lrow;
         asm volatile("" : "+v"(lr));
         const int h = min(r * RPR + lr, HROWS_PAD - 1);
-        const int hy = (h * (CT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;
-        const int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
+        const int hy = (h * (SHIFT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;
+        const int q = (lane & 7) ^ ((hx >> 1) & 7);
+        int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
+        int cbyte = (chunk * 8 + q) * 32;                            // byte offset of this piece's 8 channels within its pixel
+        if (S2) {                                                     // virtual channel -> (sub-pixel parity, real channel)
+            const int vch = chunk * 64 + q * 8, cr = d.Cin >> 2;
+            const int par = vch / cr;                                 // (cr is a power of two >= 64: a chunk never straddles parities)
+            iy = 2 * iy + (par >> 1); ix = 2 * ix + (par & 1);
+            cbyte = (vch - par * cr) * 4;
+        }
         int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
         int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
         ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
         const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
-        const int q = (lane & 7) ^ ((hx >> 1) & 7);
         Pend p;
-        p.goff = (((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + 3)) + (chunk * 8 + q) * 8) * 4u;      // byte offset (< 2^32, checked on the host)
+        p.goff = (((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + (S2 ? 3 : 5))) + cbyte);      // byte offset (< 2^32, checked on the host)
         p.ok = (h < HROWS) & (inb | refl);
         p.r0 = *(const float4*)((const char*)inf + p.goff); p.r1 = *(const float4*)((const char*)inf + p.goff + 16);
         if (RES) { p.s0 = *(const float4*)((const char*)resf + p.goff); p.s1 = *(const float4*)((const char*)resf + p.goff + 16); }
@@ -126,17 +140,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     };
     float* nlds = (float*)(smem + 2 * STAGE_BYTES);
     auto stage_norm = [&](const TileAt& ta, int slot) {
-        for (int i = tid; i < d.Cin / 2; i += NT) {              // float4 = 2 channels x (mean, rstd) -> (scale, shift)
-            const float4 v = *(const float4*)(d.in_norm + (long)ta.n * d.Cin * 2 + i * 4);
+        const int creal = S2 ? d.Cin >> 2 : d.Cin;
+        for (int i = tid; i < creal / 2; i += NT) {              // float4 = 2 channels x (mean, rstd) -> (scale, shift)
+            const float4 v = *(const float4*)(d.in_norm + (long)ta.n * creal * 2 + i * 4);
             *(float4*)(nlds + slot * 512 + i * 4) = make_float4(v.y, -v.x * v.y, v.w, -v.z * v.w);
         }
     };
     auto store_piece = [&](int slot, int stage_off, int r, const Pend& p) {
         const int row = min(r * RPR + lrow, HROWS_PAD - 1);
-        const int phy = (row * (CT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
+        const int phy = (row * (SHIFT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
         float a[8] = {p.r0.x, p.r0.y, p.r0.z, p.r0.w, p.r1.x, p.r1.y, p.r1.z, p.r1.w};
         if (NORM) {
-            const int cq = (p.goff >> 5) & ((1 << d.lc8) - 1);                     // chunk * 8 + q
+            const int cq = (p.goff >> 5) & ((1 << (d.lc8 - (S2 ? 2 : 0))) - 1);    // the piece's (real) 8-channel group
             const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
             const float lo = d.in_relu ? 0.f : -3.0e38f;
 #pragma unroll
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         // fp4 plane: this thread holds source chunk q (channels 8q .. 8q+7): 32-channel block b = q >> 2, dword q & 3;
         // 16-byte position (2b + {lo 0, hi 1}) ^ key, key = conflict-free swizzle of the fragment reads (see a_qfrag)
         const int q = (lane & 7) ^ ((phx >> 1) & 7);
-        const int key = CT ? ((phy + 2 * (phx >> 2)) & 3) : ((phx >> 1) & 3);
+        const int key = SHIFT ? ((phy + 2 * (phx >> 2)) & 3) : ((phx >> 1) & 3);
         const int qo = stage_off + A_BYTES + row * QROWB + ((((q >> 2) << 1) ^ key) << 4) + ((q & 3) << 2);
         *(unsigned*)(smem + qo) = qlo;
         *(unsigned*)(smem + (qo ^ 16)) = qhi;
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // RING substep slices and substep u re-loads the slot that substep u - 1 has just finished with (slice u + RING - 1); the MX
     // fragments of group g (32 k-values, MFMAs at the end of substep 2g + 1) are re-loaded with group g + 1 early in substep 2g + 2.
     // Each substep issues its loads row by row between its MFMAs.
-    constexpr int RING = CT ? 4 : 3;
+    constexpr int RING = SHIFT ? 4 : 3;
     static_assert(SLOTS % RING == 0, "ring / buffer positions of a substep must not depend on the chunk");
     static_assert(WTN == 128 && TN == 4 && TM == 4, "the weight streams are grouped per 128 output channels (one wave column)");
     const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
@@ -221,11 +236,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 
     // A fragment addresses (see conv3x3_halo_rb.hip); fp4 plane: per-lane base per tap column (+ tap row for CT) with the swizzle key
     const int fr = lane & 31, fh = lane >> 5;
-    int vt[3], vq[CT ? 4 : 3];
+    int vt[3], vq[SHIFT ? 4 : 3];
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
         vt[tx] = ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * ROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 7)) << 4);
-    if (!CT) {
+    if (!SHIFT) {
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx)
             vq[tx] = A_BYTES + ((wm * (WTM / 16) + (fr >> 4)) * HW_ + (fr & 15)) * QROWB + ((fh ^ ((((fr & 15) + tx) >> 1) & 3)) << 4);
@@ -242,14 +257,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         return *(const f16x8*)(smem + (vt[tx] ^ (kk << 5)) + (i * 2 * HW_ + ty * HW_ + tx) * ROWB);
     };
     auto a_qfrag = [&](int i, int ty, int tx, int ms) -> v4i {
-        const int base = CT ? vq[ty * 2 + tx] : vq[tx];
-        return *(const v4i*)(smem + (base ^ (ms << 5) ^ (CT ? ((i & 1) << 5) : 0)) + (i * 2 * HW_ + ty * HW_ + tx) * QROWB);
+        const int base = SHIFT ? vq[ty * 2 + tx] : vq[tx];
+        return *(const v4i*)(smem + (base ^ (ms << 5) ^ (SHIFT ? ((i & 1) << 5) : 0)) + (i * 2 * HW_ + ty * HW_ + tx) * QROWB);
     };
     auto flip_stage = [&](int delta) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) vt[k] += delta;
 #pragma unroll
-        for (int k = 0; k < (CT ? 4 : 3); ++k) vq[k] += delta;
+        for (int k = 0; k < (SHIFT ? 4 : 3); ++k) vq[k] += delta;
     };
     // E8M0 scales of the activation side: lanes 0-31 carry a_lo (stored * 2^c_lo_exp), lanes 32-63 a_hi (stored * 2^-c_hi_exp)
     const int a_scale = fh ? 127 + d.c_hi_exp : 127 - d.c_lo_exp;
@@ -304,10 +319,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 const int pair = CT ? ((wq / (d.phase_cout >> 5)) & 1) : 0;
                 ct_mask[j] = pair == 0 ? ((j & 1) ? 0xFu : 0x1u) : ((j & 1) ? 0x5u : 0x3u);
             }
+            // (S2) shifts with a non-zero weight block for this chunk's sub-pixel parity: dy = -1 (ty 0) needs odd input rows, dx = -1 odd columns
+            unsigned s2_mask = 0xFu;
+            if (S2) { const int par = (c * 64) / (d.Cin >> 2); s2_mask = (par & 2 ? 0xFu : 0xCu) & (par & 1 ? 0xFu : 0xAu); }
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
-                const int ty = CT ? (t >> 1) : t / 3, tx = CT ? (t & 1) : t - ty * 3;
-                const int nty = CT ? ((t + 1) >> 1) : (t + 1) / 3, ntx = CT ? ((t + 1) & 1) : (t + 1) - nty * 3;
+                const int ty = SHIFT ? (t >> 1) : t / 3, tx = SHIFT ? (t & 1) : t - ty * 3;
+                const int nty = SHIFT ? ((t + 1) >> 1) : (t + 1) / 3, ntx = SHIFT ? ((t + 1) & 1) : (t + 1) - nty * 3;
                 // k-substep index (fp16 array) and tile of substep u of this chunk, u >= SLOTS: the first substeps of the chunk staged now
                 // (after the very last one this fetches the first slices again: unconditional loads keep the code straight-line)
                 auto ks_of = [&](int u) -> long { return u < SLOTS ? (long)((u >> 2) * cin16 + c * 4 + (u & 3)) : (long)(sc * 4 + (u - SLOTS)); };
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         // for the next substep (single-buffered: 16 registers instead of 32)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            if (!(GDT_C_ABL & 8) && (!CT || ((ct_mask[j] >> t) & 1u)))
+                            if (!(GDT_C_ABL & 8) && (!CT || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u)))
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                if (!CT || ((ct_mask[j] >> t) & 1u)) {
+                                if ((!CT || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u))) {
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
                                 }
                         }
@@ -435,14 +453,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         const int m = wm * WTM + i * 32 + row;
                         const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
-                        if ((y < d.H) & (x < d.W) & (colq < d.Cout)) {
+                        if ((y < GH) & (x < GW) & (colq < d.Cout)) {
                             if (d.stats) {
                                 st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
                                 st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
                             }
                             size_t o;
                             if (CT) o = (size_t)((cur.n * d.OH + 2 * y + (ct_ph >> 1)) * d.OW + 2 * x + (ct_ph & 1)) * d.phase_cout + ct_co;
-                            else o = (size_t)((cur.n * d.H + y) * d.W + x) * d.Cout + colq;
+                            else o = (size_t)((cur.n * GH + y) * GW + x) * d.Cout + colq;
                             if (!CT && resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                             if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                             *(float4*)(outp + o) = v;
@@ -484,10 +502,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     }
 }
 
-template <int MODE, bool CT = false>
+template <int MODE, int FORM = 0>
 int launch_c(const ConvLaunch& d, hipStream_t stream) {
     constexpr int BN = 256, WGM = 2, WGN = 2;       // 4 waves of 128 pixels x 128 channels, one per SIMD (512 registers each)
-    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
+    const int gh = FORM == 2 ? d.OH : d.H, gw = FORM == 2 ? d.OW : d.W;
+    const int tiles = d.N * ((gw + 15) / 16) * ((gh + PH - 1) / PH), ntn = d.CoutPad / BN;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static int cus = 0;
     if (!cus) {
@@ -495,11 +514,11 @@ int launch_c(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     const int grid = vblocks < cus ? vblocks : cus;
-    hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, CT>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, d, vblocks);
+    hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -561,6 +580,32 @@ bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d) {
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
     d.dbg = 0;
-    if (!d.in_norm) return launch_c<0, true>(d, stream);
-    return d.in_res ? launch_c<3, true>(d, stream) : launch_c<1, true>(d, stream);
+    if (!d.in_norm) return launch_c<0, 1>(d, stream);
+    return d.in_res ? launch_c<3, 1>(d, stream) : launch_c<1, 1>(d, stream);
+}
+
+// Stride-2 form (S2): Conv2d(k3, s2, p1, zero padding) over the virtual space-to-depth view of its input.  The launch descriptor carries
+// the VIRTUAL channel count (Cin = 4 x real, lc8 likewise, Kpad = 16 x real, 4 "taps" = input shifts; weights of Op::s2), H / W the real
+// input size, OH / OW the output the patches tile.  Real Cin 64 or 128 (a 64-channel chunk must not straddle two sub-pixel parities; a folded
+// InstanceNorm keeps its table of the REAL channels in the 256-entry slots), 256-wide output tiles (Cout 128 is padded with zero columns).
+bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_C"); return e ? atoi(e) : 1; }();   // 0 off
+    if (mode == 0 || !d.w_cfrag || !d.wmx_a || !d.wmx_b || !d.out || d.out_f32 || d.res || d.phase_cout || d.pool2 || d.pad_reflect) return false;
+    const int cr = d.Cin >> 2;
+    if ((cr != 64 && cr != 128) || d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.CoutPad % 256 != 0 || d.Cout % 8 != 0) return false;
+    if (d.OH != (d.H - 1) / 2 + 1 || d.OW != (d.W - 1) / 2 + 1) return false;
+    if ((d.in_res || d.in_out) && !d.in_norm) return false;
+    if (d.stats && ((d.OH & 15) || (d.OW & 15))) return false;
+    if ((long)d.N * d.H * d.W * cr >= (1L << 30) || (long)d.N * d.OH * d.OW * d.Cout >= (1L << 32)) return false;
+    const long tiles = (long)d.N * ((d.OW + 15) / 16) * ((d.OH + 15) / 16);
+    const double useful = (double)d.OH * d.OW / ((double)((d.OH + 15) / 16 * 16) * ((d.OW + 15) / 16 * 16));
+    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();
+    return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
+}
+
+int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
+    ConvLaunch d = d_in;
+    d.dbg = 0;
+    if (!d.in_norm) return launch_c<0, 2>(d, stream);
+    return d.in_out ? launch_c<5, 2>(d, stream) : launch_c<1, 2>(d, stream);
 }

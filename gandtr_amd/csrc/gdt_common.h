@@ -134,4 +134,6 @@ bool gdt_conv_halo_c_eligible(const ConvLaunch& d);         // conv3x3_halo_c.hi
 int gdt_launch_conv_halo_c(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)
+int gdt_launch_conv_halo_c_s2(const ConvLaunch& d, hipStream_t stream);
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

@@ -55,6 +55,8 @@ struct Op {
     bool rowsplit = false; int rs_cout8 = 0; size_t rs_bias_off = 0;
     // ConvTranspose2d(k3,s2,p1,op1) as ONE GEMM: columns = 4 sub-pixel phases x cout, K = 4 input shifts x cin (conv_igemm_rb.hip)
     bool has_ctf = false; PackedPhase ctf; size_t ctf_bias_off = 0;
+    // f16c: Conv2d(k3, s2, p1) as a 2x2-shift conv over the virtual space-to-depth input (conv3x3_halo_c.hip, FORM 2): K = 4 shifts x 4 cin
+    bool has_s2 = false; PackedPhase s2; size_t s2_bias_off = 0; int s2_cout_pad = 0;
     // maxpool
     int k = 0, s = 0, p = 0;
     // gem
@@ -144,6 +146,7 @@ struct Step {
     int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
     bool wb;         // INORM folded into a conv that also writes the normalised tensor out (residual / further consumers)
     bool ctf;        // CONV (transposed): runs as the single fused-phase launch
+    bool s2;         // CONV (stride 2, f16c): runs as the shift form over the virtual space-to-depth input
     int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
     bool skip;       // MAXPOOL fused into its producer
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
@@ -187,6 +190,13 @@ void ctf_geometry(const gdt_net* net, const Op& o, int n, const Tensor& ti, Conv
     d.M = n * d.OHg * d.OWg;
 }
 
+// the stride-2 shift form (see Op::s2): virtual channel count, 4 shift "taps", real H / W in, output grid as the patch grid
+void s2_geometry(const gdt_net* net, const Op& o, int n, const Tensor& ti, ConvLaunch& d) {
+    conv_geometry(net, o, o.s2, n, ti, d);
+    d.Cin = 4 * o.cin_pad; d.lc8 = ilog2(o.cin_pad / 8) + 2;
+    d.CoutPad = o.s2_cout_pad; d.pad_reflect = 0;
+}
+
 // shape inference, fusion decisions and workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
 int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     auto& T = net->tensors;
@@ -194,7 +204,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -254,6 +264,15 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         // record sets the finalize kernel sums: one per phase pair
         if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
     }
+    for (int i = 0; i < nops && net->precision == 2; ++i) {
+        const Op& o = ops[i];
+        if (o.kind != OP_CONV || !o.has_s2) continue;
+        ConvLaunch d{};
+        s2_geometry(net, o, N, T[o.in], d);
+        d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;                  // non-null markers only
+        d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
+        if (gdt_conv_halo_c_s2_eligible(d)) plan.steps[i].s2 = true;
+    }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
     static const bool allow_norm_fusion = [] { const char* e = getenv("GDT_NORM_FUSION"); return !e || atoi(e) != 0; }();
@@ -292,6 +311,16 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
             d.in_norm = (const float*)net; d.in_res = oj.res >= 0 ? (const f16*)net : nullptr;
             if (consumers[oj.out] == 1 && gdt_conv_halo_c_ct_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            continue;
+        }
+        if (plan.steps[k].s2) {
+            if (oj.res >= 0) continue;
+            ConvLaunch d{};
+            s2_geometry(net, ok, N, T[ok.in], d);
+            d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;
+            d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
+            d.in_norm = (const float*)net; d.in_out = wb ? (f16*)net : nullptr;
+            if (gdt_conv_halo_c_s2_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
             continue;
         }
         if (net->precision == 2) {                 // f16c: the compensated halo kernel folds norm (+ReLU, +residual, +write-back)
@@ -714,6 +743,38 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         const int khw = cd.kh * cd.kw;
         pack(ph, [&](int co, int c, int t) { return weight[((size_t)co * cd.cin + c) * khw + t]; });
         o.phases.push_back(ph);
+        if (net->precision == 2 && cd.stride == 2 && cd.kh == 3 && cd.kw == 3 && cd.pad == 1 && !cd.pad_reflect && !cd.out_f32_nchw &&
+            residual_tensor < 0 && (cin_pad == 64 || cin_pad == 128) && cd.cin == cin_pad) {
+            // shift form: K index = shift * 4cin + parity * cin + c, shift = (dy+1)*2 + (dx+1) with dy, dx in {-1, 0}, parity = py*2 + px of the
+            // input pixel (2R + py, 2C + px); kernel row ky = 0 for (dy -1, py 1), 1 for (0, 0), 2 for (0, 1), none for (-1, 0); columns alike
+            PackedPhase& sp = o.s2;
+            sp.ntaps = 4; sp.TW = 2; sp.dy0 = -1; sp.dys = 1; sp.dx0 = -1; sp.dxs = 1; sp.Kpad = 16 * cin_pad;
+            o.s2_cout_pad = (cd.cout + 255) / 256 * 256;
+            std::vector<float> wf((size_t)o.s2_cout_pad * sp.Kpad, 0.f);
+            auto tap_of = [](int shift, int par) { return shift == 0 ? (par == 1 ? 0 : -1) : (par == 0 ? 1 : 2); };
+            for (int co = 0; co < cd.cout; ++co)
+                for (int t = 0; t < 4; ++t)
+                    for (int par = 0; par < 4; ++par) {
+                        const int ky = tap_of(t >> 1, par >> 1), kx = tap_of(t & 1, par & 1);
+                        if (ky < 0 || kx < 0) continue;
+                        for (int c = 0; c < cd.cin; ++c)
+                            wf[(size_t)co * sp.Kpad + (size_t)t * 4 * cin_pad + (size_t)par * cin_pad + c] =
+                                weight[((size_t)co * cd.cin + c) * 9 + ky * 3 + kx] * scale[co];
+                    }
+            std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
+            pack_mx(wf, o.s2_cout_pad, sp.Kpad, ma, mb, msc, wc);
+            sp.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
+            sp.wmx_a_off = net->blob_append(ma.data(), ma.size());
+            sp.wmx_b_off = net->blob_append(mb.data(), mb.size());
+            sp.wmx_s_off = sp.wmx_b_off;
+            sp.has_mx = true;
+            if (has_shift) {
+                std::vector<float> bp(o.s2_cout_pad, 0.f);
+                std::copy(shift.begin(), shift.end(), bp.begin());
+                o.s2_bias_off = net->blob_append(bp.data(), bp.size() * sizeof(float));
+            }
+            o.has_s2 = true;
+        }
     } else {
         // o = 2i - 1 + k.  Even outputs (parity 0): k = 1, i = y.  Odd outputs: k = 0 (i = y + 1) and k = 2 (i = y).
         for (int py = 0; py < 2; ++py)
@@ -1024,6 +1085,17 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     } else
                     rc = gdt_conv_halo_ct_eligible(d) ? gdt_launch_conv_halo_ct(d, st) : gdt_launch_conv_igemm_rb(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
+                    break;
+                }
+                if (stp.s2) {                   // stride-2 conv as the shift form over the virtual space-to-depth input (conv3x3_halo_c.hip)
+                    s2_geometry(net, o, n, ti, d);
+                    d.bias = o.has_bias ? (const float*)(net->dev_blob + o.s2_bias_off) : nullptr;
+                    d.out = tptr(o.out); d.out_f32 = nullptr; d.w = nullptr; d.w_lo = nullptr; d.w_frag = nullptr;
+                    d.w_cfrag = net->dev_blob + o.s2.wc_off; d.wmx_a = net->dev_blob + o.s2.wmx_a_off; d.wmx_b = d.wmx_s = net->dev_blob + o.s2.wmx_b_off;
+                    d.c_lo_exp = 12; d.c_hi_exp = 0;
+                    d.stats_tile_base = 0;
+                    rc = gdt_launch_conv_halo_c_s2(d, st);
+                    if (net->profiling) net->last_variant[stp.op] = 990256;
                     break;
                 }
                 int phase_idx = 0;

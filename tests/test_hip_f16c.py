@@ -88,6 +88,44 @@ def test_halo_c_transposed(cuda_device, cin, cout, norm, res):
     assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 4e-4
 
 
+@pytest.mark.parametrize("cin,cout,norm,tapped,bn", [(64, 128, False, False, False), (64, 128, True, False, False), (128, 256, True, True, False),
+                                                      (64, 128, False, False, True)])
+def test_halo_c_stride2(cuda_device, cin, cout, norm, tapped, bn):
+    """Conv2d(k3, s2, p1, zero padding) -- the generator's two down-sampling layers (p2p_networks.py:274-280) -- on the compensated
+    kernel's stride-2 form (2x2-shift conv over the virtual space-to-depth input), with the producer's InstanceNorm + ReLU folded in
+    (and written back when the normalised tensor has another consumer), statistics of its own output, or folded BatchNorm + ReLU"""
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+    t = net.instance_norm(t0, relu=True) if norm else t0
+    wt = _g(0, "w", (cout, cin, 3, 3), 0.05)
+    bias = None if bn else _g(0, "b", (cout,), 0.2)
+    bnp = None
+    if bn:
+        bnp = (synth._uniform(0, "g", (cout,), 0.5, 1.5), _g(0, "be", (cout,), 0.2), _g(0, "m", (cout,), 0.2), synth._uniform(0, "v", (cout,), 0.5, 1.5))
+    out = net.conv(t, wt, bias, bn=bnp, stride=2, pad=1, relu=bn)
+    taps = [net.output_nchw(out)]
+    if not bn:
+        taps.append(net.output_nchw(net.instance_norm(out, relu=True)))
+    if tapped:
+        taps.append(net.output_nchw(t))
+    net.finalize()
+    x = synth.synth_input(1, (8, 3, 128, 128))
+    outs = net.forward(x.to(cuda_device))
+    a = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
+    if norm:
+        a = F.relu(F.instance_norm(a, eps=1e-5))
+    ref = F.conv2d(a, wt.double(), None if bn else bias.double(), stride=2, padding=1)
+    if bn:
+        ref = F.relu(F.batch_norm(ref, bnp[2].double(), bnp[3].double(), bnp[0].double(), bnp[1].double(), training=False, eps=1e-5))
+    assert outs[taps[0]].shape == ref.shape == (8, cout, 64, 64)
+    assert _rel(outs[taps[0]].double().cpu(), ref) < 2e-4
+    if not bn:
+        assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 3e-4
+    if tapped:
+        assert _rel(outs[taps[2]].double().cpu(), a) < 1e-5
+
+
 def test_f16c_small_geometries_fall_back_to_the_exact_split(cuda_device):
     """below the patch kernels' tile threshold / channel counts the mode runs the generic f16x3 kernels: same answers as f16x3"""
     sd = synth.generator_state(0, "instance", ngf=16, n_blocks=3)
