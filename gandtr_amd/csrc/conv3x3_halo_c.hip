@@ -30,6 +30,11 @@
 #ifndef GDT_C_ABL
 #define GDT_C_ABL 0
 #endif
+// transposed form: skip the all-zero (shift, phase) weight blocks under a run-time (wave-uniform) mask?  Measured: the branches around
+// the MFMAs of a one-wave-per-SIMD loop cost ~190 spilled registers; issuing the zero blocks (16/9 of the MFMAs) is faster.
+#ifndef GDT_C_CT_SKIP
+#define GDT_C_CT_SKIP 0
+#endif
 
 namespace {
 
@@ -69,8 +74,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
     // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
     // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
-    constexpr int SLOTS = NTAP * 4, SPR = SLOTS / (NR + 1);
-    static_assert(SPR >= 1 && NR * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
+    // (the shift forms have 16 substeps for 10 rounds, one substep apart: they keep DEPTH = 2 rounds in flight instead)
+    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? 2 : 1, SPR = SLOTS / (NR + DEPTH);
+    static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM == 4 && WTM == 128 && (TN == 2 || TN == 4), "tile shape (one 128-row statistics record per wave row)");
@@ -284,7 +290,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
     for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
     __syncthreads();
-    Pend pend = load_piece(cur, 0, 0);      // (placeholder value: overwritten before its first use)
+    Pend pend[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) pend[k] = load_piece(cur, 0, 0);      // (placeholder values: overwritten before their first use)
 
     f16x8 afr[TM];
     v4i aq[TM];      // (TM == TN: row block j's fragments are fetched behind the MFMAs of column j)
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     const int u = t * 4 + kk, cu = kk & 1;
                     if (!(GDT_C_ABL & 1) && u % SPR == 0) {      // halo of the next chunk: one loader round in flight, written SPR substeps after its load
                         const int r = u / SPR;
-                        if (r >= 1 && r - 1 < NR) store_piece(sslot, STAGE_BYTES - so, r - 1, pend);
-                        if (r < NR) pend = load_piece(sta, sc, r);
+                        if (r >= DEPTH && r - DEPTH < NR) store_piece(sslot, STAGE_BYTES - so, r - DEPTH, pend[r % DEPTH]);
+                        if (r < NR) pend[r % DEPTH] = load_piece(sta, sc, r);
                     }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         // for the next substep (single-buffered: 16 registers instead of 32)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            if (!(GDT_C_ABL & 8) && (!CT || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u)))
+                            if (!(GDT_C_ABL & 8) && (!CT || !GDT_C_CT_SKIP || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u)))
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                if ((!CT || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u))) {
+                                if ((!CT || !GDT_C_CT_SKIP || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u))) {
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
                                 }
                         }
