@@ -1,5 +1,6 @@
 // Launchers of the helper kernels in aux_kernels.hip (internal to the library; the public ABI is include/gandtr_hip.h).
-// `f32` selects the activation element type: 0 = fp16 NHWC (default), 1 = fp32 NHWC ("f16x3" precision mode).
+// `f32` selects the activation element type: 0 = fp16 NHWC (default), 1 = fp32 NHWC ("f16x3" / "f16c" precision modes);
+// gdt_k_pack_input also takes 2 = fp16 NHWC8 pixel words augmented with their own rounding residuals (conv_stem.hip, f16c form).
 #pragma once
 #include "gdt_common.h"
 

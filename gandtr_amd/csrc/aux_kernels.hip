@@ -50,6 +50,7 @@ struct PackArgs {
     int N, C, H, W, OH, OW;
     float rscale;          // 1 / scale_factor (torch's source-index scale when scale_factor is given)
     int resize;
+    int aug;               // fp16 output only: slots [C, 2C) of the pixel word carry (v - fp16(v)) * 2^8 (conv_stem.hip, f16c form)
     int perm[8]; float scale[8], shift[8];
 };
 
@@ -85,6 +86,11 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a) {
                                     ly1 * (lx0 * p[(long)y1 * a.W + x0] + lx1 * p[(long)y1 * a.W + x1]);
                     o[c] = v * a.scale[c] + a.shift[c];
                 }
+        }
+        if (a.aug) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < a.C) o[a.C + c] = (o[c] - (float)(f16)o[c]) * 256.f;
         }
         store8((T*)a.y + i * 8, o);
     }
@@ -482,7 +488,9 @@ int gdt_k_pack_input(const float* x, void* y, int f32, int N, int C, int H, int 
         a.scale[c] = (scale && c < C) ? scale[c] : 1.f;
         a.shift[c] = (shift && c < C) ? shift[c] : 0.f;
     }
-    LAUNCH_T(pack_input_kernel, f32, dim3(grid_for((long)N * OH * OW)), 0, st, a);
+    a.aug = f32 == 2 ? 1 : 0;
+    GDT_REQUIRE(!a.aug || 2 * C <= 8, "augmented pixel words need 2 * channels <= 8");
+    LAUNCH_T(pack_input_kernel, f32 == 1, dim3(grid_for((long)N * OH * OW)), 0, st, a);
     return GDT_OK;
 }
 

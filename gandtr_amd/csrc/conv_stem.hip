@@ -49,7 +49,12 @@ struct StemCfg {
     static constexpr int LDS = WBYTES + (HBYTES > EPI_BYTES ? HBYTES : EPI_BYTES);
 };
 
-template <int KS, int S>
+// AUG ("f16c" precision mode, fp32-class result on the same two-taps-per-k-step machinery): the 8 slots of a pixel word carry
+// [a_hi (cin values), (a - a_hi) * 2^8 (cin values), 0 ..] (written by the input pack kernel), the weight slots of a tap
+// [w_hi, w_hi * 2^-8, 0 ..] -- so the activation's fp16 rounding residual rides in the channel padding of the SAME MFMA -- and a second
+// MFMA per fragment pair with W2 = [w - w_hi, 0 ..] (fp16 subnormals keep 7-8 bits of it: plenty for a 2^-12 correction) adds the
+// weight residual.  W2 streams from L2 into registers.  Output fp32 NHWC, statistics from the fp32 values.
+template <int KS, int S, bool AUG = false>
 __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, const int ntiles) {
     using C = StemCfg<KS, S>;
     constexpr int RPW = C::RPW, TH = C::TH, HW = C::HW, NKS = C::NKS, PAD = KS / 2;
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         {
             constexpr int PF = 3;                              // fragment sets in flight
-            f16x8 af[PF][RPW], bf[PF][2];
-            auto frags = [&](int ks, f16x8 (&a)[RPW], f16x8 (&b)[2]) {
+            f16x8 af[PF][RPW], bf[PF][2], b2[PF][2];
+            auto frags = [&](int ks, f16x8 (&a)[RPW], f16x8 (&b)[2], f16x8 (&bb)[2]) {
                 const int t0 = 2 * ks, ty = t0 / KS, tx = t0 - ty * KS;
                 const bool wrap = tx == KS - 1;                // tap t0 + 1 starts the next kernel row
                 const int base = wrap ? a_bwrap : a_b16;
@@ -116,21 +121,78 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
                 for (int i = 0; i < RPW; ++i) a[i] = *(const f16x8*)(hbuf + base + ((i * S + ty) * HW + tx) * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
+                if (AUG) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bb[j] = *(const f16x8*)((const char*)d.w_frag2 + ((ks * 2 + j) * 64 + lane) * 16);
+                }
             };
 #pragma unroll
-            for (int p = 0; p < PF - 1; ++p) frags(p, af[p], bf[p]);
+            for (int p = 0; p < PF - 1; ++p) frags(p, af[p], bf[p], b2[p]);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (ks + PF - 1 < NKS) frags(ks + PF - 1, af[(ks + PF - 1) % PF], bf[(ks + PF - 1) % PF]);
+                if (ks + PF - 1 < NKS) frags(ks + PF - 1, af[(ks + PF - 1) % PF], bf[(ks + PF - 1) % PF], b2[(ks + PF - 1) % PF]);
 #pragma unroll
                 for (int i = 0; i < RPW; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
+                    {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
+                        if (AUG) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);
+                    }
             }
         }
         __syncthreads();                               // the halo has been consumed by every wave
 
+        if (AUG) {
+            // ---- fp32 epilogue: every 32 x 32 block through the wave's private 4 KB patch (XOR-swizzled, conflict-free both ways), read
+            // back with 8 lanes per pixel = whole 128-byte lines per store; a lane then owns 4 channels of 4 pixels per block
+            float* fpatch = (float*)(hbuf + wave * PATCH_BYTES);
+            float* __restrict__ outp = (float*)d.out;
+            const int pl = lane >> 3, q = lane & 7, wswz = ((fr >> 1) & 7) << 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int colq = j * 32 + 4 * q;
+                const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& a = acc[i][j];
+                        *(float4*)(fpatch + fr * 32 + ((8 * g + 4 * fh) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    }
+                    const int oy = y0 + wave * RPW + i;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = 8 * k + pl;
+                        float4 v = *(const float4*)(fpatch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        if ((oy < d.OH) & (x0 + row < d.OW)) {
+                            if (d.stats) {
+                                t1[0] += v.x; t1[1] += v.y; t1[2] += v.z; t1[3] += v.w;
+                                t2[0] += v.x * v.x; t2[1] += v.y * v.y; t2[2] += v.z * v.z; t2[3] += v.w * v.w;
+                            }
+                            if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            *(float4*)(outp + ((size_t)((n * d.OH + oy) * d.OW + x0 + row) * 64 + colq)) = v;
+                        }
+                    }
+                }
+                if (d.stats) {      // one 128-pixel record per wave (RPW == 4), merged over the 8 pixel lanes in a fixed butterfly order
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int msk = 8; msk < 64; msk <<= 1) { t1[e] += __shfl_xor(t1[e], msk); t2[e] += __shfl_xor(t2[e], msk); }
+                    if (pl == 0) {
+                        float* dst = d.stats + ((long)(d.stats_tile_base + n * (tpi * NWAVE) + r * NWAVE + wave) * 2) * 64 + colq;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { dst[e] = t1[e]; dst[64 + e] = t2[e]; }
+                    }
+                }
+            }
+            tile += SS;
+            if (tile >= span_hi) break;
+            continue;
+        }
         // ---- epilogue: per 32-pixel row block through the wave's private patch
         f16* patch = (f16*)(hbuf + wave * PATCH_BYTES);
         float s1[8], s2[8];
@@ -179,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
     }
 }
 
-template <int KS, int S>
+template <int KS, int S, bool AUG = false>
 int launch_stem(const ConvLaunch& d, hipStream_t stream) {
     using C = StemCfg<KS, S>;
     static_assert(2 * C::LDS <= 160 * 1024, "two workgroups per CU");
@@ -189,11 +251,11 @@ int launch_stem(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_kernel<KS, S, AUG>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     }
     const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + C::TH - 1) / C::TH);
     const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((conv_stem_kernel<KS, S>), dim3(grid), dim3(NT), C::LDS, stream, d, ntiles);
+    hipLaunchKernelGGL((conv_stem_kernel<KS, S, AUG>), dim3(grid), dim3(NT), C::LDS, stream, d, ntiles);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -217,4 +279,23 @@ bool gdt_conv_stem_eligible(const ConvLaunch& d) {
 int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream) {
     if (d.ntaps == 9) return launch_stem<3, 1>(d, stream);
     return d.sy == 1 ? launch_stem<7, 1>(d, stream) : launch_stem<7, 2>(d, stream);
+}
+
+// "f16c" form (AUG): the input tensor holds augmented fp16 pixel words (gdt_k_pack_input, aug = 1), weights W1 (augmented, w_frag) and W2
+// (residuals, w_frag2) in the stem fragment order; fp32 NHWC output.  Same shapes as the fp16 form.
+bool gdt_conv_stem_c_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_STEM"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || !d.w_frag || !d.w_frag2 || d.Cin != 8 || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm || d.pool2) return false;
+    if (d.sy != d.sx || d.dys != 1 || d.dxs != 1 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
+    const bool k7 = d.ntaps == 49 && d.TW == 7 && d.dy0 == -3 && d.dx0 == -3 && (d.sy == 1 || d.sy == 2);
+    const bool k3 = d.ntaps == 9 && d.TW == 3 && d.dy0 == -1 && d.dx0 == -1 && d.sy == 1;
+    if (!k7 && !k3) return false;
+    if (d.pad_reflect && (d.H <= 3 || d.W <= 3)) return false;
+    if (d.stats && (d.sy != 1 || d.OW % 32 != 0 || d.OH % 16 != 0)) return false;
+    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+}
+
+int gdt_launch_conv_stem_c(const ConvLaunch& d, hipStream_t stream) {
+    if (d.ntaps == 9) return launch_stem<3, 1, true>(d, stream);
+    return d.sy == 1 ? launch_stem<7, 1, true>(d, stream) : launch_stem<7, 2, true>(d, stream);
 }

@@ -77,6 +77,7 @@ struct ConvLaunch {
     // wmx_a [CoutPad/128][Kpad/32][4][64 lanes][16 B] and wmx_b [..][12 B]: 32 e2m3 values per lane (24 bytes) + its E8M0 block scale (1 dword) (lanes 0-31: fp16(w) of output channel
     // lane, lanes 32-63: w - fp16(w), same 32 k-values); wmx_s [CoutPad/128][Kpad/64][4][64] dwords: E8M0 block scales (byte 0 / 1 = first /
     // second 32-k block).  Activation side: a_lo is stored as fp4(a_lo * 2^c_lo_exp), a_hi as fp4(a_hi * 2^-c_hi_exp).
+    const f16* w_frag2;           // conv_stem.hip, f16c form: the weight residuals W2 = [w - fp16(w), 0 ..] in the stem fragment order
     const void* w_cfrag;          // fp16 weights grouped per 128 output channels: [CoutPad/128][Kpad/16][4][64 lanes][8 halves] (wmx_* grouped alike)
     const void* wmx_a; const void* wmx_b; const void* wmx_s;
     int c_lo_exp, c_hi_exp;
@@ -124,6 +125,8 @@ inline __host__ __device__ void gdt_ctf_column(int c, int phase_cout, int& phase
 }
 bool gdt_conv_stem_eligible(const ConvLaunch& d);          // conv_stem.hip (image -> 64 channels, variant 950000 + taps)
 int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_stem_c_eligible(const ConvLaunch& d);        // ... f16c form: augmented pixel words + residual weights, fp32 output (variant 955000 + taps)
+int gdt_launch_conv_stem_c(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_head7_eligible(const ConvLaunch& d);         // conv_head7.hip (fused 7x7 generator head, variant 920007)
 int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32

@@ -31,6 +31,7 @@ struct PackedPhase {
     size_t w_off = 0;                 // byte offset in the device weight blob
     size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
     size_t w_frag_off = 0; bool has_frag = false;   // fp16 mode, 3x3 s1 p1: copy in MFMA B-fragment order (conv3x3_halo_rb.hip)
+    size_t w_frag2_off = 0; bool has_aug = false;   // f16c stem: w_frag = augmented W1, w_frag2 = residual W2 (conv_stem.hip)
     size_t wc_off = 0, wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
@@ -146,6 +147,7 @@ struct Step {
     int norm_from;   // CONV: index of the INORM op folded into the input staging (-1: none)
     bool wb;         // INORM folded into a conv that also writes the normalised tensor out (residual / further consumers)
     bool ctf;        // CONV (transposed): runs as the single fused-phase launch
+    bool aug;        // INPUT / CONV (f16c): the image is packed as augmented fp16 pixel words for the stem kernel's f16c form
     bool s2;         // CONV (stride 2, f16c): runs as the shift form over the virtual space-to-depth input
     int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
     bool skip;       // MAXPOOL fused into its producer
@@ -204,7 +206,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -263,6 +265,22 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         }
         // record sets the finalize kernel sums: one per phase pair
         if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
+    }
+    for (int i = 0; i < nops && net->precision == 2; ++i) {          // f16c stem: the image as augmented fp16 pixel words
+        const Op& o = ops[i];
+        if (o.kind != OP_CONV || o.cd.transposed || o.rowsplit || o.phases.empty() || !o.phases[0].has_aug) continue;
+        if (o.in < 0 || ops[net->input_op].out != o.in) continue;
+        int uses = 0;
+        for (int k = 0; k < nops; ++k) {
+            uses += (ops[k].in == o.in) + (ops[k].res == o.in);
+            if (ops[k].kind == OP_HED) for (int f = 0; f < 5; ++f) uses += ops[k].feats[f] == o.in;
+        }
+        if (uses != 1) continue;
+        ConvLaunch d{};
+        conv_geometry(net, o, o.phases[0], N, T[o.in], d);
+        d.w_frag = d.w_frag2 = (const f16*)net; d.out = (f16*)net;                           // non-null markers only
+        d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
+        if (gdt_conv_stem_c_eligible(d)) { plan.steps[i].aug = true; plan.steps[net->input_op].aug = true; }
     }
     for (int i = 0; i < nops && net->precision == 2; ++i) {
         const Op& o = ops[i];
@@ -687,6 +705,33 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     }
             ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
             ph.has_frag = true;
+        } else if (net->precision == 2 && cin_pad == 8 && 2 * cd.cin <= 8 && o.cout_pad == 64 && cd.cout == 64 && !cd.transposed) {
+            // conv_stem.hip, f16c form: W1 slots of a tap = [w_hi (cin), w_hi * 2^-8 (cin), 0 ..], W2 = [w - w_hi (cin), 0 ..]; fragments as below
+            const int nks = (ph.ntaps + 1) / 2;
+            std::vector<f16> p1((size_t)o.cout_pad * ph.Kpad, (f16)0.f), p2(p1.size(), (f16)0.f);
+            for (int co = 0; co < cd.cout; ++co)
+                for (int t = 0; t < ph.ntaps; ++t)
+                    for (int c = 0; c < cd.cin; ++c) {
+                        const float w = wget(co, c, t) * scale[co];
+                        const f16 wh = (f16)w;
+                        p1[(size_t)co * ph.Kpad + (size_t)t * 8 + c] = wh;
+                        p1[(size_t)co * ph.Kpad + (size_t)t * 8 + cd.cin + c] = (f16)((float)wh * (1.f / 256.f));
+                        p2[(size_t)co * ph.Kpad + (size_t)t * 8 + c] = (f16)(w - (float)wh);
+                    }
+            std::vector<f16> f1((size_t)nks * 2 * 64 * 8, (f16)0.f), f2(f1.size(), (f16)0.f);
+            for (int ks = 0; ks < nks; ++ks)
+                for (int j = 0; j < 2; ++j)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = ks * 16 + (ln >> 5) * 8 + e;
+                            if (k < ph.Kpad) {
+                                f1[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = p1[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + k];
+                                f2[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = p2[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + k];
+                            }
+                        }
+            ph.w_frag_off = net->blob_append(f1.data(), f1.size() * sizeof(f16));
+            ph.w_frag2_off = net->blob_append(f2.data(), f2.size() * sizeof(f16));
+            ph.has_frag = true; ph.has_aug = true;
         } else if (!net->precision && cin_pad == 8 && o.cout_pad == 64 && cd.cout == 64 && !cd.transposed) {
             // conv_stem.hip: one k-step = two taps x 8 channels; fragments [ks][column block j][lane][8], zero past the last tap
             const int nks = (ph.ntaps + 1) / 2;
@@ -1052,7 +1097,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
-                rc = gdt_k_pack_input(x, tptr(o.out), f32, n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
+                rc = gdt_k_pack_input(x, tptr(o.out), stp.aug ? 2 : f32, n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
                 break;
             }
             case OP_CONV: {
@@ -1128,7 +1173,8 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                             break;
                         }
                     }
-                    if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970256; rc = gdt_launch_conv_halo_c(d, st); }
+                    if (stp.aug) { d.w_frag2 = (const f16*)(net->dev_blob + ph.w_frag2_off); variant = 955000 + ph.ntaps; rc = gdt_launch_conv_stem_c(d, st); }
+                    else if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970256; rc = gdt_launch_conv_halo_c(d, st); }
                     else rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;

@@ -126,6 +126,34 @@ def test_halo_c_stride2(cuda_device, cin, cout, norm, tapped, bn):
         assert _rel(outs[taps[2]].double().cpu(), a) < 1e-5
 
 
+@pytest.mark.parametrize("k,stride,reflect,bn", [(7, 1, True, False), (7, 1, True, True), (3, 1, False, True), (7, 2, False, True)])
+def test_stem_c(cuda_device, k, stride, reflect, bn):
+    """First layer (image -> 64 channels) in the f16c mode: the fp16 stem kernel on pixel words augmented with the activations' own
+    rounding residuals + a second MFMA with the weight residuals = an fp32-class result (1e-5 of an fp64 evaluation; single-pass
+    fp16 measures 2.5e-4), InstanceNorm statistics or folded BatchNorm + ReLU in the epilogue"""
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    w = _g(0, "w", (64, 3, k, k), 0.1)
+    bnp = None
+    if bn:
+        bnp = (synth._uniform(0, "g", (64,), 0.5, 1.5), _g(0, "be", (64,), 0.2), _g(0, "m", (64,), 0.2), synth._uniform(0, "v", (64,), 0.5, 1.5))
+    raw = net.conv(t, w, None, bn=bnp, stride=stride, pad=k // 2, reflect=reflect, relu=bn)
+    slots = [net.output_nchw(raw)]
+    if not bn:
+        slots.append(net.output_nchw(net.instance_norm(raw, relu=True)))
+    net.finalize()
+    x = synth.synth_input(5, (4, 3, 256, 256), 1.0)
+    outs = net.forward(x.to(cuda_device))
+    xi = F.pad(x.double(), (k // 2,) * 4, mode="reflect") if reflect else x.double()
+    ref = F.conv2d(xi, w.double(), stride=stride, padding=0 if reflect else k // 2)
+    if bn:
+        ref = F.relu(F.batch_norm(ref, bnp[2].double(), bnp[3].double(), bnp[0].double(), bnp[1].double(), training=False, eps=1e-5))
+    assert outs[slots[0]].shape == ref.shape
+    assert _rel(outs[slots[0]].double().cpu(), ref) < 1e-5
+    if not bn:
+        assert _rel(outs[slots[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 2e-5
+
+
 def test_f16c_small_geometries_fall_back_to_the_exact_split(cuda_device):
     """below the patch kernels' tile threshold / channel counts the mode runs the generic f16x3 kernels: same answers as f16x3"""
     sd = synth.generator_state(0, "instance", ngf=16, n_blocks=3)
