@@ -48,6 +48,11 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// F32IN ("f16c" precision mode): the input is the fp32 NHWC tensor of that mode; the halo goes through registers (load, folded
+// InstanceNorm + ReLU in fp32, ONE rounding to fp16) instead of LDS-DMA + in-place normalisation.  The product itself stays a single
+// fp16 MFMA pass: the head is the last layer, its rounding error (3.4e-4 of the output range) is not amplified by
+// anything downstream, and the mode's budget of 1e-3 holds with it (measured 4.9e-4 pre-tanh at batch 64).
+template <bool F32IN>
 __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,6 +99,43 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
 #pragma unroll
             for (int k = 0; k < 4; ++k) nv[k] = *(const float4*)(d.in_norm + ((long)n * 64 + c8 * 8) * 2 + k * 4);
         }
+        if (F32IN) {
+            // ---- halo through registers: thread t handles 8-channel group t & 7 of pixels (t >> 3) + 32 j
+            const float* __restrict__ inf = (const float*)d.in;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sc[2 * k] = d.in_norm ? nv[k].y : 1.f; sh[2 * k] = d.in_norm ? -nv[k].x * nv[k].y : 0.f;
+                sc[2 * k + 1] = d.in_norm ? nv[k].w : 1.f; sh[2 * k + 1] = d.in_norm ? -nv[k].z * nv[k].w : 0.f;
+            }
+            const float lo = (d.in_norm && d.in_relu) ? 0.f : -3.0e38f;
+            int t8 = tid >> 3;
+            asm volatile("" : "+v"(t8));
+#pragma unroll 4
+            for (int j = 0; j < (HPIX + NT / 8 - 1) / (NT / 8); ++j) {
+                const int hp = t8 + j * (NT / 8);
+                const int hy = (hp * 1725) >> 16, hx = hp - hy * HWD;
+                const int iy = y0 - 3 + hy, ix = x0 - 3 + hx;
+                int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
+                int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
+                ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
+                const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+                const bool ok = (hp < HPIX) & (inb | refl);
+                const float* src = inf + ((size_t)((n * d.H + ry) * d.W + rx) * 64 + c8 * 8);
+                const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+                const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float p0 = fmaxf(fmaf(a[2 * k], sc[2 * k], sh[2 * k]), lo), p1 = fmaxf(fmaf(a[2 * k + 1], sc[2 * k + 1], sh[2 * k + 1]), lo);
+                    unsigned w;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(p0), "v"(p1));
+                    o[k] = ok ? w : 0u;
+                }
+                if (hp < LROWS) *(u32x4*)(smem + hp * 128 + ((c8 ^ ((hp >> 1) & 7)) << 4)) = o;
+            }
+            lds_barrier();
+        } else {
         // ---- halo: 67 wave-wide 1 KB DMA rounds (reflect / zero padding resolved in the source address)
         if (!(d.dbg & 8) || tile == span_lo + slot) {
 #pragma unroll 1
@@ -145,6 +187,8 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                 if (hp < LROWS) *(u32x4*)pp = o;
             }
             lds_barrier();
+        }
+
         }
 
         // ---- GEMM over the kernel rows: 2 or 3 independent accumulator chains per wave
@@ -213,7 +257,8 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
     static const int wgs = [] { const char* e = getenv("GDT_HEAD7_WGS"); return e ? atoi(e) : 2; }();
@@ -221,7 +266,8 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_HEAD7_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch dd = d;
     dd.dbg = dbg;
-    hipLaunchKernelGGL(conv_head7_kernel, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    if (d.in_f32) hipLaunchKernelGGL(conv_head7_kernel<true>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    else hipLaunchKernelGGL(conv_head7_kernel<false>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

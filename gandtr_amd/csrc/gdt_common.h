@@ -81,6 +81,7 @@ struct ConvLaunch {
     const void* w_cfrag;          // fp16 weights grouped per 128 output channels: [CoutPad/128][Kpad/16][4][64 lanes][8 halves] (wmx_* grouped alike)
     const void* wmx_a; const void* wmx_b; const void* wmx_s;
     int c_lo_exp, c_hi_exp;
+    int in_f32;                   // conv_head7.hip: `in` is the fp32 NHWC tensor of the f16c mode (rounded to fp16 once, while staging)
     int stagger_us;               // conv3x3_halo_c.hip: start-up delay step between the four workgroup phase groups (0: none)
     int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
                                   //      written to output pixel (2y + py, 2x + px); Cout / CoutPad count GEMM columns (conv_igemm_rb.hip)

@@ -341,8 +341,15 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             if (gdt_conv_halo_c_s2_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
             continue;
         }
+        if (net->precision == 2 && ok.rowsplit) {  // f16c head: the fused 7x7 kernel normalises while it stages its fp32 input
+            ConvLaunch h{};
+            conv_geometry(net, ok, ok.phases[0], N, T[ok.in], h);
+            h.w_frag = ok.phases[0].has_frag ? (const f16*)net : nullptr; h.out_f32 = (float*)net; h.Cout = ok.cd.cout;
+            if (!wb && oj.res < 0 && gdt_conv_head7_eligible(h)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            continue;
+        }
         if (net->precision == 2) {                 // f16c: the compensated halo kernel folds norm (+ReLU, +residual, +write-back)
-            if (ok.rowsplit || !ok.phases[0].has_mx) continue;
+            if (!ok.phases[0].has_mx) continue;
             ConvLaunch d{};
             conv_geometry(net, ok, ok.phases[0], N, T[ok.in], d);
             d.w = (const f16*)net; d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;         // non-null markers only
@@ -768,7 +775,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                         }
             ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
             if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
-            if (!net->precision && cin_pad == 64 && cd.kh == 7 && cd.kw == 7 && o.cout_pad == 32) {
+            if (net->precision != 1 && cin_pad == 64 && cd.kh == 7 && cd.kw == 7 && o.cout_pad == 32) {
                 // conv_head7.hip keeps the whole matrix in registers: B fragment ks of lane (fh, fr) = column fr, k = ks*16 + fh*8 ..
                 const int nks = ph.Kpad / 16;
                 std::vector<f16> pf((size_t)nks * 64 * 8);
@@ -1162,9 +1169,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
-                    if (o.rowsplit && !f32) {           // fused head kernel: GEMM over the kernel rows + combine + activation in one launch
+                    if (o.rowsplit && net->precision != 1) {           // fused head kernel (f16c: fp32 input, rounded once while staging): GEMM over the kernel rows + combine + activation in one launch
                         ConvLaunch h = d;
-                        h.out = nullptr; h.out_f32 = (float*)outputs[o.slot]; h.Cout = o.cd.cout; h.act = o.cd.act;
+                        h.out = nullptr; h.out_f32 = (float*)outputs[o.slot]; h.Cout = o.cd.cout; h.act = o.cd.act; h.in_f32 = f32;
                         h.bias = o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr;
                         if (gdt_conv_head7_eligible(h)) {
                             rc = gdt_launch_conv_head7(h, st);

@@ -154,6 +154,29 @@ def test_stem_c(cuda_device, k, stride, reflect, bn):
         assert _rel(outs[slots[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 2e-5
 
 
+@pytest.mark.parametrize("norm,act", [(True, 0), (True, 1), (False, 0)])
+def test_head7_f32_input(cuda_device, norm, act):
+    """Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7) + Tanh, p2p_networks.py:309-311) in the f16c mode: the fused head kernel
+    reads the mode's fp32 tensor, folds the producer's InstanceNorm + ReLU and rounds to fp16 ONCE while staging; the product is a
+    single fp16 pass (last layer: its 3e-4 is not amplified downstream) -- gate 6e-4 of the pre-activation range"""
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    t0 = net.conv(t, _g(0, "w0", (64, 3, 1, 1), 0.7))
+    t = net.instance_norm(t0, relu=True) if norm else t0
+    w, b = _g(0, "w", (3, 64, 7, 7), 0.02), _g(0, "b", (3,), 0.1)
+    slot = net.conv(t, w, b, pad=3, reflect=True, out_f32=True, act=act)
+    net.finalize()
+    x = synth.synth_input(7, (4, 3, 128, 160))
+    got = net.forward(x.to(cuda_device))[slot].double().cpu()
+    a = F.conv2d(x.double(), _g(0, "w0", (64, 3, 1, 1), 0.7).double())
+    if norm:
+        a = F.relu(F.instance_norm(a, eps=1e-5))
+    pre = F.conv2d(F.pad(a, (3,) * 4, mode="reflect"), w.double(), b.double())
+    ref = torch.tanh(pre) if act else pre
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 6e-4 * float(pre.abs().max())
+
+
 def test_f16c_small_geometries_fall_back_to_the_exact_split(cuda_device):
     """below the patch kernels' tile threshold / channel counts the mode runs the generic f16x3 kernels: same answers as f16x3"""
     sd = synth.generator_state(0, "instance", ngf=16, n_blocks=3)
