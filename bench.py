@@ -115,12 +115,16 @@ def timed(fn, steps, warmup, dev, distributed):
 
 
 def kernel_name(variant):
+    if variant >= 990000:
+        return "conv3x3_halo_c_kernel<256>[stride-2]"
     if variant >= 980000:
         return "conv3x3_halo_c_kernel<256>[transposed]"
     if variant >= 970000:
         return "conv3x3_halo_c_kernel<%d>" % (variant - 970000)
     if variant >= 960000:
         return "conv3x3_halo_rb_kernel<256>[transposed]"
+    if variant >= 955000:
+        return "conv_stem_kernel<%d taps>[f16c]" % (variant - 955000)
     if variant >= 950000:
         return "conv_stem_kernel<%d taps>" % (variant - 950000)
     if variant >= 940000:

@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
-    m = re.search(r"(conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
         g = re.search(r"(clahe_\w+_kernel|resample_\w+_kernel|reduce_kernel)(<[^>]*>)?", name)      # section-8f rows
         if g:
@@ -28,10 +28,13 @@ def short(name):
         return "%s<%s,%s>%s" % (base, a[0], a[1], "[norm]" if len(a) > 4 and a[4] == "true" else "")
     if base in ("conv3x3_halo_kernel", "conv3x3_halo_x3_kernel"):
         return "%s<%s>" % (base, a[1])
+    if base == "conv3x3_halo_c_kernel":          # <BN, WGM, WGN, MODE, FORM>
+        form = {"0": "", "1": "[transposed]", "2": "[stride-2]"}.get(a[4] if len(a) > 4 else "0", "")
+        return "%s<%s>%s[mode %s]" % (base, a[0], form, a[3])
     if base == "conv3x3_halo_rb_kernel":
         return "%s<%s>%s[mode %s]" % (base, a[0], "[transposed]" if len(a) > 4 and a[4] == "true" else "", a[3])
     if base == "conv_stem_kernel":
-        return "%s<%d taps>" % (base, int(a[0]) ** 2)
+        return "%s<%d taps>%s" % (base, int(a[0]) ** 2, "[f16c]" if len(a) > 2 and a[2] == "true" else "")
     if base == "conv_igemm_rb_kernel":
         return "%s<%s>%s" % (base, a[0], "[norm]" if a[3] == "true" else "")
     return "%s<%s>" % (base, a[0])
