@@ -127,6 +127,8 @@ def kernel_name(variant):
         return "conv_stem_kernel<%d taps>[f16c]" % (variant - 955000)
     if variant >= 950000:
         return "conv_stem_kernel<%d taps>" % (variant - 950000)
+    if variant >= 945000:
+        return "conv1x1_rb_kernel"
     if variant >= 940000:
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
     if variant >= 930000:

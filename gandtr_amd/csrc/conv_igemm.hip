@@ -325,6 +325,7 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
     if (d.pool2) GDT_REQUIRE(gdt_conv_halo_rb_eligible(d) || gdt_conv_halo_eligible(d), "fused max pool needs a patch kernel");
     if (gdt_conv_stem_eligible(d)) { *variant = 950000 + d.ntaps; return gdt_launch_conv_stem(d, stream); }
+    if (gdt_conv_1x1_rb_eligible(d)) { *variant = 945128; return gdt_launch_conv_1x1_rb(d, stream); }
     if (!gdt_conv_halo_rb_eligible(d) && !gdt_conv_halo_eligible(d) && gdt_conv_igemm_rb_eligible(d)) return gdt_launch_conv_igemm_rb(d, stream, variant);
     if (d.in_norm && !gdt_conv_halo_eligible(d))
         GDT_REQUIRE(gdt_conv_igemm_norm_eligible(d), "fused input normalisation needs Cin == 64 and whole 256-row tiles per image here");

@@ -115,6 +115,8 @@ int gdt_launch_conv_halo_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* variant);
 int gdt_conv_igemm_rb_stats_sets(const ConvLaunch& d);
+bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d);        // conv1x1_rb.hip (streaming 1x1 conv, variant 945128)
+int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream);
 // fused transposed conv (phase_cout > 0): GEMM column c -> (sub-pixel phase, output channel).  Each 64-column wave slice pairs
 // a cheap phase with an expensive one -- 32 columns of phase 0 (1 input shift) + 32 of phase 3 (4 shifts), or 1 + 2 (2 + 2) --
 // so that skipping the all-zero (shift, phase) weight blocks leaves every wave 4-5 of its 8 block-steps.

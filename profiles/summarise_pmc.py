@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
-    m = re.search(r"(conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(conv1x1_rb_kernel|conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
         g = re.search(r"(clahe_\w+_kernel|resample_\w+_kernel|reduce_kernel)(<[^>]*>)?", name)      # section-8f rows
         if g:
@@ -24,6 +24,8 @@ def short(name):
     if not args:
         return base
     a = [v.strip() for v in args[1:-1].split(",")]
+    if base == "conv1x1_rb_kernel":
+        return base
     if base == "conv_igemm_kernel":
         return "%s<%s,%s>%s" % (base, a[0], a[1], "[norm]" if len(a) > 4 and a[4] == "true" else "")
     if base in ("conv3x3_halo_kernel", "conv3x3_halo_x3_kernel"):
