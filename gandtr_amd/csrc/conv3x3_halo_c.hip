@@ -33,7 +33,7 @@
 // transposed form: skip the all-zero (shift, phase) weight blocks under a run-time (wave-uniform) mask?  Measured: the branches around
 // the MFMAs of a one-wave-per-SIMD loop cost ~190 spilled registers; issuing the zero blocks (16/9 of the MFMAs) is faster.
 #ifndef GDT_C_CT_SKIP
-#define GDT_C_CT_SKIP 0
+#define GDT_C_CT_SKIP 1
 #endif
 
 namespace {
@@ -320,13 +320,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             lo16 = lane_bytes(16); lo12 = lane_bytes(12);
             // (CT) which input shifts t have a non-zero weight block for column block j of this wave (gdt_ctf_column: 64-column
             // slices pair a cheap phase with an expensive one)
-            unsigned ct_mask[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int wq = (cur.tile_n * BN + wn * WTN + j * 32) >> 6;
-                const int pair = CT ? ((wq / (d.phase_cout >> 5)) & 1) : 0;
-                ct_mask[j] = pair == 0 ? ((j & 1) ? 0xFu : 0x1u) : ((j & 1) ? 0x5u : 0x3u);
-            }
+            // -- with gdt_ctc_column() column block j of EVERY wave is sub-pixel phase j of 32 output channels: the masks are
+            // compile-time constants (phase 0: shift 0; 1: + dx; 2: + dy; 3: all four), the zero blocks cost neither MFMAs nor loads
+            auto ct_on = [](int t, int j) -> bool { return !CT || !GDT_C_CT_SKIP || (((0xF531u >> (4 * j)) >> t) & 1u) != 0; };
+            // tap of substep u (u >= SLOTS: the first substeps of the chunk staged now)
+            auto t_of = [](int u) -> int { return u < SLOTS ? (u >> 2) : ((u - SLOTS) >> 2); };
             // (S2) shifts with a non-zero weight block for this chunk's sub-pixel parity: dy = -1 (ty 0) needs odd input rows, dx = -1 odd columns
             unsigned s2_mask = 0xFu;
             if (S2) { const int par = (c * 64) / (d.Cin >> 2); s2_mask = (par & 2 ? 0xFu : 0xCu) & (par & 1 ? 0xFu : 0xAu); }
@@ -352,16 +350,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         // for the next substep (single-buffered: 16 registers instead of 32)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            if (!(GDT_C_ABL & 8) && (!CT || !GDT_C_CT_SKIP || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u)))
+                            if (!(GDT_C_ABL & 8) && ct_on(t, j) && (!S2 || ((s2_mask >> t) & 1u)))
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
-                        if (!(GDT_C_ABL & 4)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
+                        if (!(GDT_C_ABL & 4) && ct_on(t_of(u + RING - 1), i)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
                         if (kk < 3) afr[i] = a_frag(i, ty, tx, kk + 1);
                         else if (t < NTAP - 1) afr[i] = a_frag(i, nty, ntx, 0);
                         if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all four columns are re-loaded
                             aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first two rows: >= 24 MFMAs before their first use)
-                            if (!(GDT_C_ABL & 2) && i < 2) { load_bq(2 * i, tn_of(u), ks_of(u)); load_bq(2 * i + 1, tn_of(u), ks_of(u)); }
+                            if (!(GDT_C_ABL & 2) && i < 2) {
+                                if (ct_on(t_of(u), 2 * i)) load_bq(2 * i, tn_of(u), ks_of(u));
+                                if (ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
+                            }
                         }
                     }
                     if (!(GDT_C_ABL & 2) && cu == 1) {          // the correction product of the 32 k-values just done
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                if ((!CT || !GDT_C_CT_SKIP || ((ct_mask[j] >> t) & 1u)) && (!S2 || ((s2_mask >> t) & 1u))) {
+                                if (ct_on(t, j) && (!S2 || ((s2_mask >> t) & 1u))) {
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
                                 }
                         }
@@ -442,8 +443,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;         // this lane's 4 channels after the transpose
                 const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
                 int ct_ph = 0, ct_co = 0;
-                if (CT) gdt_ctf_column(colq, d.phase_cout, ct_ph, ct_co);
-                if (!CT || (j & 1) == 0) {
+                if (CT) gdt_ctc_column(colq, ct_ph, ct_co);
+                if (!CT || j == 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
                 }
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         }
                     }
                 }
-                if (d.stats && (!CT || (j & 1) == 1)) {
+                if (d.stats && (!CT || j == TN - 1)) {        // (CT: the wave's four blocks are the four phases of the same channels)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -483,10 +484,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     if (pl == 0 && colq < d.Cout) {
                         float* dst;
                         if (!CT) dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + colq;
-                        else {              // one record set per phase pair (the wave's two blocks of a 64-column slice), the finalize kernel sums the sets
-                            const int pair = ((colq >> 6) / (d.phase_cout >> 5)) & 1;
-                            dst = d.stats + ((long)(pair * (ntm * WGM) + cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
-                        }
+                        else dst = d.stats + ((long)(cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
                         const int cstride = CT ? d.phase_cout : d.Cout;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { dst[e] = st1[e]; dst[cstride + e] = st2[e]; }

@@ -126,6 +126,11 @@ inline __host__ __device__ void gdt_ctf_column(int c, int phase_cout, int& phase
     phase = pair == 0 ? (j ? 3 : 0) : (j ? 2 : 1);
     co = (wq % wpp) * 32 + (c & 31);
 }
+// ... in conv3x3_halo_c.hip (f16c mode): a wave's 128-column slice holds the four phases of 32 output channels, block j = phase j
+inline __host__ __device__ void gdt_ctc_column(int c, int& phase, int& co) {
+    phase = (c >> 5) & 3;
+    co = (c >> 7) * 32 + (c & 31);
+}
 bool gdt_conv_stem_eligible(const ConvLaunch& d);          // conv_stem.hip (image -> 64 channels, variant 950000 + taps)
 int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_stem_c_eligible(const ConvLaunch& d);        // ... f16c form: augmented pixel words + residual weights, fp32 output (variant 955000 + taps)

@@ -247,7 +247,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
         if (net->precision == 2) {                 // f16c: the compensated LDS-resident form whenever eligible
             d.w_frag = nullptr; d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net;
-            if (o.ctf.has_mx && gdt_conv_halo_c_ct_eligible(d)) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
+            if (o.ctf.has_mx && gdt_conv_halo_c_ct_eligible(d)) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 1; }
             continue;
         }
         // GDT_CONV_CTF: 0 never, 1 (default) the LDS-resident kernel whenever eligible and the generic persistent GEMM only where
@@ -854,7 +854,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             if (net->precision == 2) wf.assign(pk.size(), 0.f);
             for (int col = 0; col < ncol; ++col) {
                 int phase, co;
-                gdt_ctf_column(col, cd.cout, phase, co);
+                if (net->precision == 2) gdt_ctc_column(col, phase, co); else gdt_ctf_column(col, cd.cout, phase, co);
                 const int py = phase >> 1, px = phase & 1;
                 for (int dy = 0; dy < 2; ++dy)
                     for (int dx = 0; dx < 2; ++dx) {
@@ -886,7 +886,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             if (!net->precision) { cf.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16)); cf.has_frag = true; }
             if (has_shift) {
                 std::vector<float> b4(ncol);
-                for (int i = 0; i < ncol; ++i) { int ph, co; gdt_ctf_column(i, cd.cout, ph, co); b4[i] = shift[co]; }
+                for (int i = 0; i < ncol; ++i) { int ph, co; if (net->precision == 2) gdt_ctc_column(i, ph, co); else gdt_ctf_column(i, cd.cout, ph, co); b4[i] = shift[co]; }
                 o.ctf_bias_off = net->blob_append(b4.data(), b4.size() * sizeof(float));
             }
             o.has_ctf = true;
