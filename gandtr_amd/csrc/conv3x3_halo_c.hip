@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "gdt_common.h"
 
 // timing-only ablations (profiles/experiments): compile with -DGDT_C_ABL=<bits>; results are wrong by design
@@ -32,6 +34,12 @@
 #endif
 // transposed form: skip the all-zero (shift, phase) weight blocks under a run-time (wave-uniform) mask?  Measured: the branches around
 // the MFMAs of a one-wave-per-SIMD loop cost ~190 spilled registers; issuing the zero blocks (16/9 of the MFMAs) is faster.
+#ifndef GDT_C_DEPTH
+#define GDT_C_DEPTH 1           // loader rounds in flight per thread, 3x3 form (modes without / with residual + write-back)
+#endif
+#ifndef GDT_C_DEPTH_RES
+#define GDT_C_DEPTH_RES 1
+#endif
 #ifndef GDT_C_CT_SKIP
 #define GDT_C_CT_SKIP 1
 #endif
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
     // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
     // (the shift forms have 16 substeps for 10 rounds, one substep apart: they keep DEPTH = 2 rounds in flight instead)
-    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? 2 : 1, SPR = SLOTS / (NR + DEPTH);
+    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? 2 : ((MODE & 6) ? GDT_C_DEPTH_RES : GDT_C_DEPTH), SPR = SLOTS / (NR + DEPTH);
     static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -437,60 +445,81 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             const int fr_e = lane_e & 31, fh_e = lane_e >> 5, pl = lane_e >> 3, q = lane_e & 7;
             const bool relu_now = d.relu != 0;
             const int wswz = ((fr_e >> 1) & 7) << 2;
-            float st1[4], st2[4];
+            // Two bodies: tiles that lie wholly inside the output with no epilogue residual (every tile of the generator) run
+            // branch-free -- no per-store bounds test, statistics always accumulated, ReLU as a max with 0 or -inf; the checked body keeps
+            // the ragged edges and the residual read.  Output offsets: one 32-bit element offset per pixel row of the lane (16 per tile).
+            const bool full_tile = (cur.y0 + 16 <= GH) & (cur.x0 + 16 <= GW) & (cur.tile_n * BN + wn * WTN + WTN <= d.Cout) & (resp == nullptr);
+            auto epilogue = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                // pixel row (i, k) of this lane: y = y0 + 8 wm + 2 i + (k >> 1), x = x0 + 8 (k & 1) + pl -> one per-lane base offset plus a
+                // uniform term per (i, k)
+                const int yb = cur.y0 + wm * 8, xb = cur.x0 + pl;
+                const unsigned obase = CT ? (unsigned)((cur.n * d.OH + 2 * yb) * d.OW + 2 * xb) * (unsigned)d.phase_cout
+                                          : (unsigned)((cur.n * GH + yb) * GW + xb) * (unsigned)d.Cout;
+                auto roff = [&](int i, int k) -> unsigned {
+                    return CT ? (unsigned)((2 * (2 * i + (k >> 1))) * d.OW + 16 * (k & 1)) * (unsigned)d.phase_cout
+                              : (unsigned)((2 * i + (k >> 1)) * GW + 8 * (k & 1)) * (unsigned)d.Cout;
+                };
+                auto row_ok = [&](int i, int k) -> bool { return (yb + 2 * i + (k >> 1) < GH) & (xb + 8 * (k & 1) < GW); };
+                const float lo = relu_now ? 0.f : -__builtin_inff();
+                float st1[4], st2[4];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;         // this lane's 4 channels after the transpose
-                const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                int ct_ph = 0, ct_co = 0;
-                if (CT) gdt_ctc_column(colq, ct_ph, ct_co);
-                if (!CT || j == 0) {
+                for (int j = 0; j < TN; ++j) {
+                    const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;         // this lane's 4 channels after the transpose
+                    const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    int ct_ph = 0, ct_co = 0;
+                    if (CT) gdt_ctc_column(colq, ct_ph, ct_co);
+                    const unsigned coff = CT ? (unsigned)(((ct_ph >> 1) * d.OW + (ct_ph & 1)) * d.phase_cout + ct_co) : (unsigned)colq;
+                    if (!CT || j == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x16& a = acc[i][j];
-                        *(float4*)(patch + fr_e * 32 + ((8 * g + 4 * fh_e) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                        for (int e = 0; e < 4; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = 8 * k + pl;
-                        float4 v = *(const float4*)(patch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        const int m = wm * WTM + i * 32 + row;
-                        const int y = cur.y0 + (m >> 4), x = cur.x0 + (m & 15);
-                        if ((y < GH) & (x < GW) & (colq < d.Cout)) {
-                            if (d.stats) {
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& a = acc[i][j];
+                            *(float4*)(patch + fr_e * 32 + ((8 * g + 4 * fh_e) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int row = 8 * k + pl;
+                            float4 v = *(const float4*)(patch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            const unsigned o = obase + roff(i, k) + coff;
+                            if (FAST) {
                                 st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
                                 st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
+                                v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+                                *(float4*)(outp + o) = v;
+                            } else if (row_ok(i, k) & (colq < d.Cout)) {
+                                if (d.stats) {
+                                    st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
+                                    st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
+                                }
+                                if (!CT && resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                                if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                                *(float4*)(outp + o) = v;
                             }
-                            size_t o;
-                            if (CT) o = (size_t)((cur.n * d.OH + 2 * y + (ct_ph >> 1)) * d.OW + 2 * x + (ct_ph & 1)) * d.phase_cout + ct_co;
-                            else o = (size_t)((cur.n * GH + y) * GW + x) * d.Cout + colq;
-                            if (!CT && resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-                            if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                            *(float4*)(outp + o) = v;
+                        }
+                    }
+                    if (d.stats && (!CT || j == TN - 1)) {        // (CT: the wave's four blocks are the four phases of the same channels)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
+                        if (pl == 0 && colq < d.Cout) {
+                            float* dst;
+                            if (!CT) dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + colq;
+                            else dst = d.stats + ((long)(cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
+                            const int cstride = CT ? d.phase_cout : d.Cout;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { dst[e] = st1[e]; dst[cstride + e] = st2[e]; }
                         }
                     }
                 }
-                if (d.stats && (!CT || j == TN - 1)) {        // (CT: the wave's four blocks are the four phases of the same channels)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
-                    if (pl == 0 && colq < d.Cout) {
-                        float* dst;
-                        if (!CT) dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + colq;
-                        else dst = d.stats + ((long)(cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
-                        const int cstride = CT ? d.phase_cout : d.Cout;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { dst[e] = st1[e]; dst[cstride + e] = st2[e]; }
-                    }
-                }
-            }
+            };
+            if (full_tile) epilogue(std::true_type()); else epilogue(std::false_type());
         } else {
             float sacc = 0.f;
 #pragma unroll
