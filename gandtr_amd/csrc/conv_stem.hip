@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "gdt_common.h"
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -25,6 +27,9 @@
 
 namespace {
 
+#ifndef GDT_STEM_PF_AUG
+#define GDT_STEM_PF_AUG 3
+#endif
 constexpr int TW = 32;                     // output tile width (one 32-pixel MFMA block per output row)
 constexpr int NWAVE = 4, NT = NWAVE * 64;
 constexpr int CP = 72;                     // halves per pixel row of the wave-private transpose patch (64 + 8)
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         {
-            constexpr int PF = 3;                              // fragment sets in flight
+            constexpr int PF = AUG ? GDT_STEM_PF_AUG : 3;      // fragment sets in flight (the f16c form carries a second weight set: 256 registers)
             f16x8 af[PF][RPW], bf[PF][2], b2[PF][2];
             auto frags = [&](int ks, f16x8 (&a)[RPW], f16x8 (&b)[2], f16x8 (&bb)[2]) {
                 const int t0 = 2 * ks, ty = t0 / KS, tx = t0 - ty * KS;
@@ -121,9 +126,11 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
                 for (int i = 0; i < RPW; ++i) a[i] = *(const f16x8*)(hbuf + base + ((i * S + ty) * HW + tx) * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
-                if (AUG) {
+                if (AUG) {          // uniform base + 32-bit lane offset (opaque: keeps the zero-extension next to the load, i.e. the
+                    unsigned lo = lane * 16;        //  scalar-base addressing form; per-lane 64-bit addresses for 50 fragments spilled 34 registers)
+                    asm volatile("" : "+v"(lo));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bb[j] = *(const f16x8*)((const char*)d.w_frag2 + ((ks * 2 + j) * 64 + lane) * 16);
+                    for (int j = 0; j < 2; ++j) bb[j] = *(const f16x8*)((const char*)d.w_frag2 + (size_t)((ks * 2 + j) * 1024) + lo);
                 }
             };
 #pragma unroll
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);   // D[cout][pixel]
                         if (AUG) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);
                     }
+                if (AUG) __builtin_amdgcn_sched_barrier(0);        // (keeps the residual-weight loads of later steps from being hoisted: 70 spilled registers)
             }
         }
         __syncthreads();                               // the halo has been consumed by every wave
@@ -149,46 +157,61 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(const ConvLaunch d, co
             float* fpatch = (float*)(hbuf + wave * PATCH_BYTES);
             float* __restrict__ outp = (float*)d.out;
             const int pl = lane >> 3, q = lane & 7, wswz = ((fr >> 1) & 7) << 2;
+            // interior tiles (all of them when OH, OW are multiples of the tile) run a branch-free body: no per-store bounds test,
+            // statistics always accumulated, ReLU as a max with 0 or -inf
+            const bool full_tile = (y0 + TH <= d.OH) & (x0 + TW <= d.OW);
+            const float lo = d.relu ? 0.f : -__builtin_inff();
+            const unsigned obase = (unsigned)((n * d.OH + y0 + wave * RPW) * d.OW + x0 + pl) * 64u + 4u * q;      // (< 2^32 elements: eligibility)
+            auto epilogue = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int colq = j * 32 + 4 * q;
-                const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) {
+                    const int colq = j * 32 + 4 * q;
+                    const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) {
+                    for (int i = 0; i < RPW; ++i) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x16& a = acc[i][j];
-                        *(float4*)(fpatch + fr * 32 + ((8 * g + 4 * fh) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
-                    }
-                    const int oy = y0 + wave * RPW + i;
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& a = acc[i][j];
+                            *(float4*)(fpatch + fr * 32 + ((8 * g + 4 * fh) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                        }
+                        const int oy = y0 + wave * RPW + i;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = 8 * k + pl;
-                        float4 v = *(const float4*)(fpatch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if ((oy < d.OH) & (x0 + row < d.OW)) {
-                            if (d.stats) {
+                        for (int k = 0; k < 4; ++k) {
+                            const int row = 8 * k + pl;
+                            float4 v = *(const float4*)(fpatch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            const unsigned o = obase + (unsigned)((i * d.OW + 8 * k) * 64 + j * 32);
+                            if (FAST) {
                                 t1[0] += v.x; t1[1] += v.y; t1[2] += v.z; t1[3] += v.w;
                                 t2[0] += v.x * v.x; t2[1] += v.y * v.y; t2[2] += v.z * v.z; t2[3] += v.w * v.w;
+                                v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+                                *(float4*)(outp + o) = v;
+                            } else if ((oy < d.OH) & (x0 + row < d.OW)) {
+                                if (d.stats) {
+                                    t1[0] += v.x; t1[1] += v.y; t1[2] += v.z; t1[3] += v.w;
+                                    t2[0] += v.x * v.x; t2[1] += v.y * v.y; t2[2] += v.z * v.z; t2[3] += v.w * v.w;
+                                }
+                                if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                                *(float4*)(outp + o) = v;
                             }
-                            if (d.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                            *(float4*)(outp + ((size_t)((n * d.OH + oy) * d.OW + x0 + row) * 64 + colq)) = v;
+                        }
+                    }
+                    if (d.stats) {      // one 128-pixel record per wave (RPW == 4), merged over the 8 pixel lanes in a fixed butterfly order
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int msk = 8; msk < 64; msk <<= 1) { t1[e] += __shfl_xor(t1[e], msk); t2[e] += __shfl_xor(t2[e], msk); }
+                        if (pl == 0) {
+                            float* dst = d.stats + ((long)(d.stats_tile_base + n * (tpi * NWAVE) + r * NWAVE + wave) * 2) * 64 + colq;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { dst[e] = t1[e]; dst[64 + e] = t2[e]; }
                         }
                     }
                 }
-                if (d.stats) {      // one 128-pixel record per wave (RPW == 4), merged over the 8 pixel lanes in a fixed butterfly order
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int msk = 8; msk < 64; msk <<= 1) { t1[e] += __shfl_xor(t1[e], msk); t2[e] += __shfl_xor(t2[e], msk); }
-                    if (pl == 0) {
-                        float* dst = d.stats + ((long)(d.stats_tile_base + n * (tpi * NWAVE) + r * NWAVE + wave) * 2) * 64 + colq;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { dst[e] = t1[e]; dst[64 + e] = t2[e]; }
-                    }
-                }
-            }
+            };
+            if (full_tile) epilogue(std::true_type()); else epilogue(std::false_type());
             tile += SS;
             if (tile >= span_hi) break;
             continue;
