@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         p.goff = (((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + (S2 ? 3 : 5))) + cbyte);      // byte offset (< 2^32, checked on the host)
         p.ok = (h < HROWS) & (inb | refl);
         p.r0 = *(const float4*)((const char*)inf + p.goff); p.r1 = *(const float4*)((const char*)inf + p.goff + 16);
-        if (RES) { p.s0 = *(const float4*)((const char*)resf + p.goff); p.s1 = *(const float4*)((const char*)resf + p.goff + 16); }
+        if (RES && !(GDT_C_ABL & 32)) { p.s0 = *(const float4*)((const char*)resf + p.goff); p.s1 = *(const float4*)((const char*)resf + p.goff + 16); }
         return p;
     };
     float* nlds = (float*)(smem + 2 * STAGE_BYTES);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         }
         // write-back of the transformed tensor (every piece stores the value of its clamped source pixel: identical bits from
         // neighbouring patches, no branch)
-        if (WB) {
+        if (WB && !(GDT_C_ABL & 16)) {
             *(float4*)((char*)wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
             *(float4*)((char*)wbf + p.goff + 16) = make_float4(a[4], a[5], a[6], a[7]);
         }
