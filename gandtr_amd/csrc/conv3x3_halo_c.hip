@@ -537,6 +537,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     }
 }
 
+// timing-only ablation knob: GDT_C_DBG=4 skips the epilogue
+static int c_dbg() { static const int v = [] { const char* e = getenv("GDT_C_DBG"); return e ? atoi(e) : 0; }(); return v; }
+
 template <int MODE, int FORM = 0>
 int launch_c(const ConvLaunch& d, hipStream_t stream) {
     constexpr int BN = 256, WGM = 2, WGN = 2;       // 4 waves of 128 pixels x 128 channels, one per SIMD (512 registers each)
@@ -614,7 +617,7 @@ bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d) {
 
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
-    d.dbg = 0;
+    d.dbg = c_dbg();
     if (!d.in_norm) return launch_c<0, 1>(d, stream);
     return d.in_res ? launch_c<3, 1>(d, stream) : launch_c<1, 1>(d, stream);
 }
@@ -640,7 +643,7 @@ bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
 
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
-    d.dbg = 0;
+    d.dbg = c_dbg();
     if (!d.in_norm) return launch_c<0, 2>(d, stream);
     return d.in_out ? launch_c<5, 2>(d, stream) : launch_c<1, 2>(d, stream);
 }
