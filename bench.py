@@ -303,8 +303,8 @@ def dry_run(a, real_stdout):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)       # 100 x 12 ms: a 1.2 s timed region (DVFS-steady)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gen-batch", type=int, default=64)
     ap.add_argument("--r101-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
