@@ -159,6 +159,12 @@ def main():
         r2, _ = rate(lambda: ingest.ingest(photo, 1024, mean, std, clahe_clip=1.0), 1, steps=200, warmup=10)
         out["next_ingest_1200x1600_to_1024"] = {"images_per_s": r, "us": round(1e6 / r, 1), "with_clahe_images_per_s": r2,
                                                 "with_clahe_us": round(1e6 / r2, 1)}
+        rng = np.random.default_rng(1)                      # a list of 64 photos of mixed sizes through the batched entry point (one call)
+        mixed = [torch.from_numpy(rng.integers(0, 256, (int(h), int(w), 3)).astype(np.uint8)).to(dev)
+                 for h, w in zip(rng.integers(700, 1500, 64), rng.integers(900, 2000, 64))]
+        r3, _ = rate(lambda: ingest.ingest_many(mixed, 1024, mean, std), 64, steps=20, warmup=3)
+        out["next_ingest_1200x1600_to_1024"]["mixed_64_batched_images_per_s"] = r3
+        del mixed
         # "next" row: learned whitening, D = 2048, 20 k vectors, 8 k pairs (float64)
         from gandtr_amd import whiten_learn
         gq = torch.Generator(device=dev).manual_seed(0)

@@ -20,6 +20,12 @@ class ConvDesc(ctypes.Structure):
                 ("act", c_int), ("bn_eps", c_float)]
 
 
+class IngestItem(ctypes.Structure):
+    """struct gdt_ingest_item (include/gandtr_hip.h)."""
+    _fields_ = [("src", c_void_p), ("h", c_int), ("w", c_int), ("fx", c_int), ("fy", c_int), ("box", c_float * 4),
+                ("out_w", c_int), ("out_h", c_int), ("dst_hwc", c_void_p), ("dst_chw", c_void_p)]
+
+
 _FP = POINTER(c_float)
 _IP = POINTER(c_int)
 
@@ -59,6 +65,9 @@ SIGNATURES = {
     "gdt_ingest_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_ingest_resize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), c_int, c_int, c_void_p, c_void_p,
                                      POINTER(c_float), POINTER(c_float), c_void_p, c_size_t, c_void_p]),
+    "gdt_ingest_batch_workspace_bytes": (c_int, [POINTER(IngestItem), c_int, c_int, POINTER(c_size_t)]),
+    "gdt_ingest_resize_u8_batch": (c_int, [POINTER(IngestItem), c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_size_t,
+                                           c_void_p]),
     "gdt_whiten_learn_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_whiten_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                  c_void_p, c_size_t, c_void_p]),

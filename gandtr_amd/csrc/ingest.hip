@@ -12,6 +12,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -120,9 +121,9 @@ __device__ __forceinline__ unsigned clip8(int ss) { return (unsigned)min(max(ss 
 // Image.reduce((fx, fy)) over the full image; one lane per output pixel (C channels).  Partial boxes at the right / bottom edge
 // average over their own pixel count (ImagingReduceCorners).
 template <int C>
-__global__ __launch_bounds__(256) void reduce_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int h, int w, int fx,
-                                                     int fy, int oh, int ow) {
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void reduce_body(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int h, int w, int fx, int fy,
+                                            int oh, int ow, int bx, int by) {
+    const int ox = bx * 64 + (threadIdx.x & 63), oy = by * 4 + (threadIdx.x >> 6);
     if (ox >= ow || oy >= oh) return;
     const int x0 = ox * fx, y0 = oy * fy, nx = min(fx, w - x0), ny = min(fy, h - y0);
     unsigned ss[C] = {};
@@ -137,6 +138,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(const unsigned char* __rest
 #pragma unroll
     for (int c = 0; c < C; ++c)
         dst[((size_t)oy * ow + ox) * C + c] = (unsigned char)(((unsigned long long)(ss[c] + n / 2) * mult) >> 24);
+}
+template <int C>
+__global__ __launch_bounds__(256) void reduce_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int h, int w, int fx,
+                                                     int fy, int oh, int ow) {
+    reduce_body<C>(src, dst, h, w, fx, fy, oh, ow, blockIdx.x, blockIdx.y);
 }
 
 // horizontal pass: rows [first, last) of src (w pixels) -> tmp [(last - first)][ow][C]
@@ -201,14 +207,14 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __
 // row) is staged into LDS with aligned 4-byte loads (the naive kernel issues ~3 * taps byte loads per output pixel and is bound by
 // the address unit), the 64 coefficient rows once per workgroup; taps then come from LDS.  tmp rows have a padded stride.
 constexpr int H_ROWS = 16, H_MAXK = 48, HSPAN = 1536;
-__global__ __launch_bounds__(256) void resample_h3_kernel(const unsigned char* __restrict__ src, size_t src_bytes, unsigned char* __restrict__ tmp,
-                                                          int tstride, int w, int first, int rows, int ow, const int* __restrict__ bounds,
-                                                          const int* __restrict__ kk, int ksize) {
+__device__ __forceinline__ void resample_h3_body(const unsigned char* __restrict__ src, size_t src_bytes, unsigned char* __restrict__ tmp,
+                                                 int tstride, int w, int first, int rows, int ow, const int* __restrict__ bounds,
+                                                 const int* __restrict__ kk, int ksize, int bx, int by) {
     __shared__ __attribute__((aligned(16))) unsigned char px[H_ROWS][HSPAN + 8];
     __shared__ int kl[64 * H_MAXK];
     __shared__ int delta[H_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xx0 = blockIdx.x * 64, y0 = blockIdx.y * H_ROWS;
+    const int xx0 = bx * 64, y0 = by * H_ROWS;
     const int ncol = min(64, ow - xx0), nrow = min(H_ROWS, rows - y0);
     const int x_lo = bounds[2 * xx0], x_hi = bounds[2 * (xx0 + ncol - 1)] + bounds[2 * (xx0 + ncol - 1) + 1];
     const int span = (x_hi - x_lo) * 3;                                       // bytes per row (<= HSPAN, checked by the launcher)
@@ -242,14 +248,19 @@ __global__ __launch_bounds__(256) void resample_h3_kernel(const unsigned char* _
         o[0] = (unsigned char)clip8(s0); o[1] = (unsigned char)clip8(s1); o[2] = (unsigned char)clip8(s2);
     }
 }
+__global__ __launch_bounds__(256) void resample_h3_kernel(const unsigned char* __restrict__ src, size_t src_bytes, unsigned char* __restrict__ tmp,
+                                                          int tstride, int w, int first, int rows, int ow, const int* __restrict__ bounds,
+                                                          const int* __restrict__ kk, int ksize) {
+    resample_h3_body(src, src_bytes, tmp, tstride, w, first, rows, ow, bounds, kk, ksize, blockIdx.x, blockIdx.y);
+}
 
 // Vertical pass for C = 3 on rows of 4-byte-aligned stride: a lane owns four pixels (12 bytes, one 12-byte load per tap) and
 // stores 16 bytes per colour plane.
-__global__ __launch_bounds__(256) void resample_v3_kernel(const unsigned char* __restrict__ tmp, int tstride, int ow, int oh, int shift,
-                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int vertical,
-                                                          unsigned char* __restrict__ dst_hwc, float* __restrict__ dst_chw, float m0, float m1,
-                                                          float m2, float s0, float s1, float s2) {
-    const int q = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void resample_v3_body(const unsigned char* __restrict__ tmp, int tstride, int ow, int oh, int shift,
+                                                 const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int vertical,
+                                                 unsigned char* __restrict__ dst_hwc, float* __restrict__ dst_chw, float m0, float m1,
+                                                 float m2, float s0, float s1, float s2, int bx, int by) {
+    const int q = bx * 64 + (threadIdx.x & 63), yy = by * 4 + (threadIdx.x >> 6);
     if (4 * q >= ow || yy >= oh) return;
     unsigned v[12];
     if (vertical) {
@@ -298,6 +309,39 @@ __global__ __launch_bounds__(256) void resample_v3_kernel(const unsigned char* _
             else for (int j = 0; j < nv; ++j) o[j] = f[j];
         }
     }
+}
+__global__ __launch_bounds__(256) void resample_v3_kernel(const unsigned char* __restrict__ tmp, int tstride, int ow, int oh, int shift,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int vertical,
+                                                          unsigned char* __restrict__ dst_hwc, float* __restrict__ dst_chw, float m0, float m1,
+                                                          float m2, float s0, float s1, float s2) {
+    resample_v3_body(tmp, tstride, ow, oh, shift, bounds, kk, ksize, vertical, dst_hwc, dst_chw, m0, m1, m2, s0, s1, s2, blockIdx.x, blockIdx.y);
+}
+
+// ---- batched RGB path: one launch per pass for a whole list of images of different sizes (blockIdx.z = image; the grid covers the
+// largest one, the other images' surplus workgroups leave at once).  Per-image parameters sit in a descriptor array in the workspace.
+struct BatchItem {
+    const unsigned char* src; unsigned char* red; unsigned char* tmp; const unsigned char* cur; const unsigned char* vin;
+    unsigned char* dst_hwc; float* dst_chw;
+    const int* hb; const int* hk; const int* vb; const int* vk;
+    unsigned long long cur_bytes;
+    int h, w, fx, fy, rh, rw, cw, out_w, out_h, tstride, vstride, first, rows, shift, hks, vks, need_h, need_v, do_reduce;
+};
+__global__ __launch_bounds__(256) void reduce3_batch_kernel(const BatchItem* __restrict__ items) {
+    const BatchItem it = items[blockIdx.z];
+    if (!it.do_reduce || (int)blockIdx.x * 64 >= it.rw || (int)blockIdx.y * 4 >= it.rh) return;
+    reduce_body<3>(it.src, it.red, it.h, it.w, it.fx, it.fy, it.rh, it.rw, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void resample_h3_batch_kernel(const BatchItem* __restrict__ items) {
+    const BatchItem& it = items[blockIdx.z];
+    if (!it.need_h || (int)blockIdx.x * 64 >= it.out_w || (int)blockIdx.y * H_ROWS >= it.rows) return;      // (uniform per workgroup)
+    resample_h3_body(it.cur, (size_t)it.cur_bytes, it.tmp, it.tstride, it.cw, it.first, it.rows, it.out_w, it.hb, it.hk, it.hks, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void resample_v3_batch_kernel(const BatchItem* __restrict__ items, float m0, float m1, float m2, float s0, float s1,
+                                                                float s2) {
+    const BatchItem& it = items[blockIdx.z];
+    if ((int)blockIdx.x * 256 >= it.out_w || (int)blockIdx.y * 4 >= it.out_h) return;
+    resample_v3_body(it.vin, it.vstride, it.out_w, it.out_h, it.shift, it.vb, it.vk, it.vks, it.need_v, it.dst_hwc, it.dst_chw, m0, m1, m2, s0, s1,
+                     s2, blockIdx.x, blockIdx.y);
 }
 
 constexpr size_t ALIGN = 256;
@@ -381,9 +425,143 @@ int run_ingest(const unsigned char* src, int h, int w, int fx, int fy, const flo
     return GDT_OK;
 }
 
+// ---- batched entry: per-image plans, one descriptor upload, three launches (box reduction / horizontal / vertical pass) when every
+// image can take the RGB fast paths; otherwise the images run one after the other through run_ingest (same results either way)
+struct BatchPlan {
+    std::vector<IngestPlan> plans;
+    std::vector<size_t> offs;         // workspace offset of image i's region
+    size_t desc_bytes = 0, total = 0;
+};
+
+int plan_batch(const gdt_ingest_item* items, int n, int c, BatchPlan& bp) {
+    GDT_REQUIRE(items != nullptr && n >= 1 && n <= 65535, "ingest batch: 1..65535 images");
+    bp.plans.resize(n);
+    bp.offs.resize(n);
+    bp.desc_bytes = align_up((size_t)n * sizeof(BatchItem));
+    size_t off = bp.desc_bytes;
+    for (int i = 0; i < n; ++i) {
+        int rc = plan_ingest(items[i].h, items[i].w, c, items[i].fx, items[i].fy, items[i].out_w, items[i].out_h, bp.plans[i]);
+        if (rc != GDT_OK) return rc;
+        bp.offs[i] = off;
+        off += bp.plans[i].total;
+    }
+    bp.total = off + ALIGN;
+    return GDT_OK;
+}
+
+int check_item(const gdt_ingest_item& it, const IngestPlan& p, float* box) {
+    GDT_REQUIRE(it.src != nullptr && (it.dst_hwc != nullptr || it.dst_chw != nullptr), "ingest: null buffer");
+    for (int k = 0; k < 4; ++k) box[k] = it.box[k];
+    if (box[0] == 0.f && box[1] == 0.f && box[2] == 0.f && box[3] == 0.f) {      // all zero = the whole (reduced) image
+        box[2] = (float)p.rw; box[3] = (float)p.rh;
+    }
+    GDT_REQUIRE(box[0] >= 0.f && box[1] >= 0.f && box[2] <= (float)p.rw && box[3] <= (float)p.rh && box[2] > box[0] && box[3] > box[1],
+                "ingest: box outside the (reduced) image");
+    return GDT_OK;
+}
+
+int run_ingest_batch(const gdt_ingest_item* items, int n, int c, const float* mean, const float* stdv, char* ws, const BatchPlan& bp,
+                     hipStream_t stream) {
+    static thread_local std::vector<BatchItem> host;
+    host.assign(n, BatchItem());
+    bool fast = c == 3;
+    int max_rw = 1, max_rh = 1, max_ow = 1, max_rows = 1, max_oh = 1;
+    bool any_reduce = false, any_h = false;
+    std::vector<float> boxes((size_t)n * 4);
+    for (int i = 0; i < n; ++i) {
+        const gdt_ingest_item& it = items[i];
+        const IngestPlan& p = bp.plans[i];
+        float* box = &boxes[(size_t)i * 4];
+        int rc = check_item(it, p, box);
+        if (rc != GDT_OK) return rc;
+        BatchItem& b = host[i];
+        char* base = ws + bp.offs[i];
+        b.src = it.src; b.red = (unsigned char*)(base + p.reduced); b.tmp = (unsigned char*)(base + p.tmp);
+        b.dst_hwc = it.dst_hwc; b.dst_chw = it.dst_chw;
+        b.h = it.h; b.w = it.w; b.fx = it.fx; b.fy = it.fy; b.rh = p.rh; b.rw = p.rw; b.out_w = it.out_w; b.out_h = it.out_h; b.tstride = p.tstride;
+        b.do_reduce = (it.fx > 1 || it.fy > 1) ? 1 : 0;
+        const int ch = b.do_reduce ? p.rh : it.h, cw = b.do_reduce ? p.rw : it.w;
+        b.cur = b.do_reduce ? b.red : it.src; b.cw = cw; b.cur_bytes = (unsigned long long)ch * cw * 3;
+        b.need_h = (it.out_w != cw || box[0] != 0.f || box[2] != (float)it.out_w) ? 1 : 0;
+        b.need_v = (it.out_h != ch || box[1] != 0.f || box[3] != (float)it.out_h) ? 1 : 0;
+        if (!fast) continue;
+        DevCoeffs kh, kv;
+        rc = axis_coeffs(ch, box[1], box[3], it.out_h, stream, kv);
+        if (rc != GDT_OK) return rc;
+        b.vb = kv.bounds; b.vk = kv.kk; b.vks = kv.ksize;
+        b.first = 0; b.rows = ch;
+        if (b.need_v) { b.first = kv.first; b.rows = kv.last - kv.first; }
+        b.vin = b.cur; b.shift = 0; b.vstride = cw * 3;
+        if (b.need_h) {
+            rc = axis_coeffs(cw, box[0], box[2], it.out_w, stream, kh);
+            if (rc != GDT_OK) return rc;
+            b.hb = kh.bounds; b.hk = kh.kk; b.hks = kh.ksize;
+            const double scale = ((double)box[2] - box[0]) / it.out_w;
+            if (((uintptr_t)b.cur & 3) != 0 || kh.ksize > H_MAXK || (64.0 * scale + kh.ksize + 4) * 3 > HSPAN) fast = false;
+            b.vin = b.tmp; b.shift = b.first; b.vstride = p.tstride;
+        }
+        if ((b.vstride & 3) != 0 || ((uintptr_t)b.vin & 3) != 0 || b.vstride < 12 * ((it.out_w + 3) / 4) ||
+            (it.dst_hwc && ((uintptr_t)it.dst_hwc & 3) != 0) || (it.dst_chw && ((uintptr_t)it.dst_chw & 15) != 0)) fast = false;
+        any_reduce |= b.do_reduce != 0; any_h |= b.need_h != 0;
+        max_rw = std::max(max_rw, p.rw); max_rh = std::max(max_rh, p.rh); max_ow = std::max(max_ow, it.out_w);
+        max_rows = std::max(max_rows, b.rows); max_oh = std::max(max_oh, it.out_h);
+    }
+    if (!fast) {                 // generic channel counts / unaligned buffers / extreme down-scaling: image by image
+        for (int i = 0; i < n; ++i) {
+            const gdt_ingest_item& it = items[i];
+            char* base = ws + bp.offs[i];
+            const float* box = &boxes[(size_t)i * 4];
+            int rc;
+            switch (c) {
+                case 1: rc = run_ingest<1>(it.src, it.h, it.w, it.fx, it.fy, box, it.out_w, it.out_h, it.dst_hwc, it.dst_chw, mean, stdv, base, bp.plans[i], stream); break;
+                case 2: rc = run_ingest<2>(it.src, it.h, it.w, it.fx, it.fy, box, it.out_w, it.out_h, it.dst_hwc, it.dst_chw, mean, stdv, base, bp.plans[i], stream); break;
+                case 3: rc = run_ingest<3>(it.src, it.h, it.w, it.fx, it.fy, box, it.out_w, it.out_h, it.dst_hwc, it.dst_chw, mean, stdv, base, bp.plans[i], stream); break;
+                default: rc = run_ingest<4>(it.src, it.h, it.w, it.fx, it.fy, box, it.out_w, it.out_h, it.dst_hwc, it.dst_chw, mean, stdv, base, bp.plans[i], stream); break;
+            }
+            if (rc != GDT_OK) return rc;
+        }
+        return GDT_OK;
+    }
+    BatchItem* dev = (BatchItem*)ws;
+    GDT_CHECK_HIP(hipMemcpyAsync(dev, host.data(), (size_t)n * sizeof(BatchItem), hipMemcpyHostToDevice, stream));
+    if (any_reduce)
+        hipLaunchKernelGGL(reduce3_batch_kernel, dim3((max_rw + 63) / 64, (max_rh + 3) / 4, n), dim3(256), 0, stream, dev);
+    if (any_h)
+        hipLaunchKernelGGL(resample_h3_batch_kernel, dim3((max_ow + 63) / 64, (max_rows + H_ROWS - 1) / H_ROWS, n), dim3(256), 0, stream, dev);
+    float m[3] = {0, 0, 0}, s[3] = {1, 1, 1};
+    for (int i = 0; i < 3; ++i) { if (mean) m[i] = mean[i]; if (stdv) s[i] = stdv[i]; }
+    hipLaunchKernelGGL(resample_v3_batch_kernel, dim3(((max_ow + 3) / 4 + 63) / 64, (max_oh + 3) / 4, n), dim3(256), 0, stream, dev, m[0], m[1], m[2],
+                       s[0], s[1], s[2]);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gdt_ingest_batch_workspace_bytes(const gdt_ingest_item* items, int n, int c, size_t* bytes) {
+    GDT_REQUIRE(bytes != nullptr, "bytes");
+    GDT_REQUIRE(c >= 1 && c <= 4, "ingest: 1..4 interleaved 8-bit channels");
+    BatchPlan bp;
+    int rc = plan_batch(items, n, c, bp);
+    if (rc != GDT_OK) return rc;
+    *bytes = bp.total;
+    return GDT_OK;
+}
+
+int gdt_ingest_resize_u8_batch(const gdt_ingest_item* items, int n, int c, const float* mean, const float* std, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    GDT_REQUIRE(c >= 1 && c <= 4, "ingest: 1..4 interleaved 8-bit channels");
+    BatchPlan bp;
+    int rc = plan_batch(items, n, c, bp);
+    if (rc != GDT_OK) return rc;
+    GDT_REQUIRE(workspace != nullptr, "ingest: null workspace");
+    if (std) for (int i = 0; i < c; ++i) GDT_REQUIRE(std[i] != 0.f, "ingest: zero std");
+    if (workspace_bytes < bp.total) { gdt_set_error("ingest: workspace too small"); return GDT_ERR_WORKSPACE; }
+    char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
+    return run_ingest_batch(items, n, c, mean, std, ws, bp, (hipStream_t)stream);
+}
 
 int gdt_ingest_workspace_bytes(int h, int w, int c, int fx, int fy, int out_w, int out_h, size_t* bytes) {
     GDT_REQUIRE(bytes != nullptr, "bytes");

@@ -101,38 +101,66 @@ def ingest(img, imsize, mean, std, clahe_clip=None, clahe_grid=8):
     return clahe.clahe_lab(unit[None], clahe_clip, clahe_grid, None, (mean, std))[0]
 
 
+def resize_many(images, plans, want_u8=True, mean_std=None, want_chw=False):
+    """``resize`` for a list of uint8 H x W x C device tensors of different sizes in ONE library call (gdt_ingest_resize_u8_batch: three
+    launches for the whole list when the images are RGB).  ``plans``: per image ``((out_w, out_h), (fx, fy), box or None)``.
+    Returns (list of uint8 outputs or None, list of fp32 C x h x w outputs or None)."""
+    lib = _hip.load()
+    if not images:
+        return ([] if want_u8 else None), ([] if want_chw else None)
+    dev, c = images[0].device, images[0].shape[2]
+    images = [img.contiguous() for img in images]
+    for img in images:
+        if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != c or img.device != dev:
+            raise ValueError("ingest needs uint8 H x W x C tensors with the same channel count on one HIP device")
+    n = len(images)
+    items = (_hip.IngestItem * n)()
+    u8 = [None] * n
+    chw = [None] * n
+    # one allocation per output kind for the whole list (views of 16-byte aligned slices): 64 small allocations cost more than the kernels
+    counts = [c * size[0] * size[1] for size, _, _ in plans]
+    starts = [0] * n
+    for i in range(1, n):
+        starts[i] = starts[i - 1] + (counts[i - 1] + 15) // 16 * 16
+    total = starts[-1] + counts[-1]
+    flat_u8 = torch.empty(total, dtype=torch.uint8, device=dev) if want_u8 else None
+    flat_f = torch.empty(total, dtype=torch.float32, device=dev) if want_chw else None
+    for i, (img, (size, factors, box)) in enumerate(zip(images, plans)):
+        it = items[i]
+        it.src, it.h, it.w = img.data_ptr(), img.shape[0], img.shape[1]
+        it.fx, it.fy = factors
+        if box is not None:
+            it.box = (ctypes.c_float * 4)(*[float(v) for v in box])
+        it.out_w, it.out_h = size
+        if want_u8:
+            u8[i] = flat_u8[starts[i]:starts[i] + counts[i]].view(size[1], size[0], c)
+            it.dst_hwc = u8[i].data_ptr()
+        if want_chw:
+            chw[i] = flat_f[starts[i]:starts[i] + counts[i]].view(c, size[1], size[0])
+            it.dst_chw = chw[i].data_ptr()
+    mean, std = mean_std if mean_std is not None else (None, None)
+    need = ctypes.c_size_t()
+    with torch.cuda.device(dev):
+        _hip.check(lib.gdt_ingest_batch_workspace_bytes(items, n, c, ctypes.byref(need)))
+        ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        _hip.check(lib.gdt_ingest_resize_u8_batch(items, n, c, _f(mean, c), _f(std, c), ws.data_ptr(), ws.numel(),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
+    return (u8 if want_u8 else None), (chw if want_chw else None)
+
+
 def ingest_many(images, imsize, mean, std, clahe_clip=None, clahe_grid=8, streams=4):
     """``ingest`` over a list of decoded images of different sizes (the reference is batch-1 for exactly that reason,
-    imageretrievalnet.py:319-322).  The images are dealt round-robin onto ``streams`` HIP streams; the caller's current stream
-    waits for all of them.  Measured: 32 k images/s for a mixed 1-3 Mpixel set with 1, 4 or 8 streams alike -- the host-side launch
-    path (~30 us per image) bounds it, not the kernels; the streams only matter when the host is faster (a C++ caller).
-    Returns a list of fp32 3 x h x w tensors in input order."""
+    imageretrievalnet.py:319-322): the resampling of the whole list is one library call / three launches (``resize_many``); only the
+    optional CLAHE still runs per image (its tile grid depends on the image size).  ``streams`` is kept for callers of the earlier
+    per-image form and ignored.  Returns a list of fp32 3 x h x w tensors in input order."""
     if not images:
         return []
-    dev = images[0].device
-    cur = torch.cuda.current_stream(dev)
-    pool = _stream_pool(dev, max(1, min(int(streams), len(images))))
-    out = [None] * len(images)
-    for s in pool:
-        s.wait_stream(cur)                       # inputs were produced on the caller's stream
-    for i, img in enumerate(images):
-        s = pool[i % len(pool)]
-        with torch.cuda.stream(s):
-            out[i] = ingest(img, imsize, mean, std, clahe_clip, clahe_grid)
-            out[i].record_stream(cur)
-    for s in pool:
-        cur.wait_stream(s)
-    return out
-
-
-_POOLS = {}
-
-
-def _stream_pool(dev, n):
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
-    if key not in _POOLS:
-        _POOLS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
-    return _POOLS[key]
+    plans = [_plan(img, imsize) for img in images]
+    if clahe_clip is None:
+        return resize_many(images, plans, want_u8=False, mean_std=(mean, std), want_chw=True)[1]
+    from . import clahe
+    unit = resize_many(images, plans, want_u8=False, want_chw=True)[1]                              # [0, 1] RGB planes
+    return [clahe.clahe_lab(u[None], clahe_clip, clahe_grid, None, (mean, std))[0] for u in unit]
 
 
 class DeviceTransform:

@@ -198,6 +198,24 @@ int gdt_ingest_resize_u8(const unsigned char* src, int h, int w, int c, int fx, 
                          unsigned char* dst_hwc, float* dst_chw, const float* mean, const float* std, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The same for a LIST of decoded images of different sizes in one call (the reference is batch-1 over exactly such lists:
+ * mdir/external/cirtorch/networks/imageretrievalnet.py:319-322, genericdataset.py:66-102).  Every item carries what
+ * gdt_ingest_resize_u8 takes per image (box all zero = the whole reduced image).  RGB images on 4-byte-aligned buffers run as
+ * three launches for the whole list (box reduction, horizontal pass, vertical pass + conversion; blockIdx.z = image) driven by a
+ * descriptor array the call uploads into the workspace; other channel counts / alignments run image by image inside the call.
+ * Results are bit-identical to the per-image entry point.  items: host array. */
+typedef struct gdt_ingest_item {
+    const unsigned char* src;      /* device, [h][w][c] uint8 */
+    int h, w, fx, fy;
+    float box[4];
+    int out_w, out_h;
+    unsigned char* dst_hwc;        /* device [out_h][out_w][c] uint8, or NULL */
+    float* dst_chw;                /* device [c][out_h][out_w] fp32, or NULL */
+} gdt_ingest_item;
+int gdt_ingest_batch_workspace_bytes(const gdt_ingest_item* items, int n, int c, size_t* bytes);
+int gdt_ingest_resize_u8_batch(const gdt_ingest_item* items, int n, int c, const float* mean, const float* std, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Learned whitening ("next" row of SURVEY.md section 8f, rank 4): the {m, P} that gdt_whiten applies
  * Replaces  whitenlearn(X, qidxs, pidxs)  (mdir/external/cirtorch/utils/whiten.py:37-70; called with float64 D x N values from

@@ -88,7 +88,7 @@ def test_hub_transform_chain_with_clahe(cuda_device):
 
 
 def test_ingest_many_matches_one_by_one(cuda_device):
-    """mixed sizes on concurrent streams == the same images one by one (bitwise), in input order"""
+    """a list of mixed sizes through the batched call == the same images one by one (bitwise), in input order"""
     rng = np.random.default_rng(9)
     shapes = [(600, 800), (333, 500), (1200, 1600), (500, 375), (768, 1024), (2001, 1333), (97, 400), (640, 640), (1024, 683)]
     imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).to(cuda_device) for h, w in shapes]
@@ -102,6 +102,30 @@ def test_ingest_many_matches_one_by_one(cuda_device):
     for a, b in zip(ref, again):
         assert torch.equal(a, b)
     assert ingest.ingest_many([], 362, MEAN, STD) == []
+
+
+def test_resize_many_matches_resize(cuda_device):
+    """the batched entry point (one call, three launches for RGB lists) against the per-image one, bitwise: plain thumbnails, a
+    box reduction (3000 x 2000 -> 362), an image that needs no resampling, a cropped box, uint8 + fp32 outputs; and a grayscale
+    list, which runs image by image inside the call"""
+    rng = np.random.default_rng(10)
+    shapes = [(600, 800), (2000, 3000), (362, 362), (97, 400), (1024, 683), (500, 375)]
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).to(cuda_device) for h, w in shapes]
+    plans = [ingest._plan(im, 362) for im in imgs]
+    assert any(p[1] != (1, 1) for p in plans) and any(p[0] == (im.shape[1], im.shape[0]) for p, im in zip(plans, imgs))
+    plans[0] = ((300, 200), (1, 1), (10.0, 20.0, 700.0, 500.0))                      # explicit crop box + its own output size
+    u8, chw = ingest.resize_many(imgs, plans, want_u8=True, mean_std=(MEAN, STD), want_chw=True)
+    for im, (size, factors, box), a, b in zip(imgs, plans, u8, chw):
+        ra, rb = ingest.resize(im, size[0], size[1], factors, box, want_u8=True, mean_std=(MEAN, STD), want_chw=True)
+        assert a.shape == ra.shape and torch.equal(a, ra)
+        assert b.shape == rb.shape and torch.equal(b, rb)
+    gray = [torch.from_numpy(rng.integers(0, 256, (h, w, 1)).astype(np.uint8)).to(cuda_device) for h, w in shapes[:3]]
+    gplans = [ingest._plan(im, 200) for im in gray]
+    gu8, _ = ingest.resize_many(gray, gplans)
+    for im, (size, factors, box), a in zip(gray, gplans, gu8):
+        assert torch.equal(a, ingest.resize(im, size[0], size[1], factors, box)[0])
+    with pytest.raises(ValueError):
+        ingest.resize_many([imgs[0], gray[0]], [plans[0], gplans[0]])                 # mixed channel counts
 
 
 def test_hub_device_transform(cuda_device):
