@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert((TM == 4 || TM == 8) && (TN == 2 || TN == 4) && TM * TN <= 16, "tile shape (128-row statistics records: one or two per wave)");
+    static_assert(TM == 4 && WTM == 128 && (TN == 2 || TN == 4), "tile shape (one 128-row statistics record per wave row)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // Each substep issues its loads row by row between its MFMAs.
     constexpr int RING = SHIFT ? 4 : 3;
     static_assert(SLOTS % RING == 0, "ring / buffer positions of a substep must not depend on the chunk");
-    static_assert(TN == 4 || TN == 2, "the weight streams are grouped per 128 output channels");
-    const int wgrp_of_wave = (wn * WTN) >> 7, wblk = ((wn * WTN) >> 5) & 3;      // the wave's 128-column weight group within the tile, its first 32-column block in it
+    static_assert(TM == 4 && (TN == 4 || TN == 2), "the weight streams are grouped per 128 output channels");
+    const int wgrp_of_wave = (wn * WTN) >> 7, wblk = ((wn * WTN) >> 5) & 3;      // 128-column group of this wave within the tile, first 32-column block in it
     const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
     typedef int v3i __attribute__((ext_vector_type(3)));
     f16x8 b[RING][TN];
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
                         if (kk < 3) afr[i] = a_frag(i, ty, tx, kk + 1);
                         else if (t < NTAP - 1) afr[i] = a_frag(i, nty, ntx, 0);
-                        if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all columns are re-loaded
-                            aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
+                        if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all four columns are re-loaded
+                            aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first two rows: >= 24 MFMAs before their first use)
                             if (!(GDT_C_ABL & 2) && 2 * i < TN) {
                                 if (ct_on(t_of(u), 2 * i)) load_bq(2 * i, tn_of(u), ks_of(u));
                                 if (ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 constexpr bool FAST = decltype(fast_tag)::value;
                 // pixel row (i, k) of this lane: y = y0 + 8 wm + 2 i + (k >> 1), x = x0 + 8 (k & 1) + pl -> one per-lane base offset plus a
                 // uniform term per (i, k)
-                const int yb = cur.y0 + wm * (WTM / 16), xb = cur.x0 + pl;
+                const int yb = cur.y0 + wm * 8, xb = cur.x0 + pl;
                 const unsigned obase = CT ? (unsigned)((cur.n * d.OH + 2 * yb) * d.OW + 2 * xb) * (unsigned)d.phase_cout
                                           : (unsigned)((cur.n * GH + yb) * GW + xb) * (unsigned)d.Cout;
                 auto roff = [&](int i, int k) -> unsigned {
@@ -463,8 +463,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 };
                 auto row_ok = [&](int i, int k) -> bool { return (yb + 2 * i + (k >> 1) < GH) & (xb + 8 * (k & 1) < GW); };
                 const float lo = relu_now ? 0.f : -__builtin_inff();
-                constexpr int NH = TM / 4;              // 128-row statistics records per wave
-                float st1[NH][4], st2[NH][4];
+                float st1[4], st2[4];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;         // this lane's 4 channels after the transpose
@@ -474,9 +473,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     const unsigned coff = CT ? (unsigned)(((ct_ph >> 1) * d.OW + (ct_ph & 1)) * d.phase_cout + ct_co) : (unsigned)colq;
                     if (!CT || j == 0) {
 #pragma unroll
-                        for (int h = 0; h < NH; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { st1[h][e] = 0.f; st2[h][e] = 0.f; }
+                        for (int e = 0; e < 4; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
                     }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
@@ -492,14 +489,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                             const unsigned o = obase + roff(i, k) + coff;
                             if (FAST) {
-                                st1[i / 4][0] += v.x; st1[i / 4][1] += v.y; st1[i / 4][2] += v.z; st1[i / 4][3] += v.w;
-                                st2[i / 4][0] += v.x * v.x; st2[i / 4][1] += v.y * v.y; st2[i / 4][2] += v.z * v.z; st2[i / 4][3] += v.w * v.w;
+                                st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
+                                st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
                                 v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
                                 *(float4*)(outp + o) = v;
                             } else if (row_ok(i, k) & (colq < d.Cout)) {
                                 if (d.stats) {
-                                    st1[i / 4][0] += v.x; st1[i / 4][1] += v.y; st1[i / 4][2] += v.z; st1[i / 4][3] += v.w;
-                                    st2[i / 4][0] += v.x * v.x; st2[i / 4][1] += v.y * v.y; st2[i / 4][2] += v.z * v.z; st2[i / 4][3] += v.w * v.w;
+                                    st1[0] += v.x; st1[1] += v.y; st1[2] += v.z; st1[3] += v.w;
+                                    st2[0] += v.x * v.x; st2[1] += v.y * v.y; st2[2] += v.z * v.z; st2[3] += v.w * v.w;
                                 }
                                 if (!CT && resp) { const float4 rv = *(const float4*)(resp + o); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                                 if (relu_now) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -509,20 +506,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     }
                     if (d.stats && (!CT || j == TN - 1)) {        // (CT: the wave's four blocks are the four phases of the same channels)
 #pragma unroll
-                        for (int h = 0; h < NH; ++h) {
+                        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
+                            for (int msk = 8; msk < 64; msk <<= 1) { st1[e] += __shfl_xor(st1[e], msk); st2[e] += __shfl_xor(st2[e], msk); }
+                        if (pl == 0 && colq < d.Cout) {
+                            float* dst;
+                            if (!CT) dst = d.stats + ((long)(d.stats_tile_base + cur.tile_m * WGM + wm) * 2) * d.Cout + colq;
+                            else dst = d.stats + ((long)(cur.tile_m * WGM + wm) * 2) * d.phase_cout + ct_co;
+                            const int cstride = CT ? d.phase_cout : d.Cout;
 #pragma unroll
-                                for (int msk = 8; msk < 64; msk <<= 1) { st1[h][e] += __shfl_xor(st1[h][e], msk); st2[h][e] += __shfl_xor(st2[h][e], msk); }
-                            if (pl == 0 && colq < d.Cout) {
-                                const int rec = cur.tile_m * (BM / 128) + wm * NH + h;          // 128-row record of the patch
-                                float* dst;
-                                if (!CT) dst = d.stats + ((long)(d.stats_tile_base + rec) * 2) * d.Cout + colq;
-                                else dst = d.stats + ((long)rec * 2) * d.phase_cout + ct_co;
-                                const int cstride = CT ? d.phase_cout : d.Cout;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { dst[e] = st1[h][e]; dst[cstride + e] = st2[h][e]; }
-                            }
+                            for (int e = 0; e < 4; ++e) { dst[e] = st1[e]; dst[cstride + e] = st2[e]; }
                         }
                     }
                 }
@@ -548,17 +541,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 // timing-only ablation knob: GDT_C_DBG=4 skips the epilogue
 static int c_dbg() { static const int v = [] { const char* e = getenv("GDT_C_DBG"); return e ? atoi(e) : 0; }(); return v; }
 
-// Four waves, one per SIMD (512 registers each: 256 accumulator AGPRs + 256 VGPRs).  TALL = false: 2 x 2 waves of 128 pixels x 128
-// channels; TALL = true: 1 x 4 waves of 256 pixels x 64 channels -- every wave reads all 256 pixels' fragments from LDS (twice the
-// LDS bytes per MFMA) and streams a quarter of the weights from L1 (half the L1 bytes per MFMA: the L1 weight stream is the scarcer
-// of the two, ~60 % of its bandwidth in the square shape).  Measured on the resblock conv: 0.422 -> 0.408 ms plain, 0.518 -> 0.485
-// with the residual + write-back staging.  (An eight-wave form, two waves of 128 x 64 per SIMD at 256 registers, runs its fp16
-// core faster -- 0.185 vs 0.243 ms -- but pays 0.09 ms for the weight stream and 0.07 for the staging: 0.443 ms complete.)
-// BN_ = 128 (output channel counts that are not a multiple of 256: the 64 -> 128 stride-2 layer): 2 x 2 waves of 128 pixels x 64 channels.
-template <int MODE, int FORM = 0, bool TALL = false, int BN_ = 256>
+template <int MODE, int FORM = 0>
 int launch_c(const ConvLaunch& d, hipStream_t stream) {
-    constexpr int BN = BN_, WGM = TALL ? 1 : 2, WGN = TALL ? 4 : 2;
-    static_assert(BN == 256 || (BN == 128 && !TALL), "tile width");
+    constexpr int BN = 256, WGM = 2, WGN = 4;       // 4 waves of 128 pixels x 128 channels, one per SIMD (512 registers each)
     const int gh = FORM == 2 ? d.OH : d.H, gw = FORM == 2 ? d.OW : d.W;
     const int tiles = d.N * ((gw + 15) / 16) * ((gh + PH - 1) / PH), ntn = d.CoutPad / BN;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -605,15 +590,6 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
     d.dbg = dbg;
     static const int stagger = [] { const char* e = getenv("GDT_C_STAGGER_US"); return e ? atoi(e) : 0; }();
     d.stagger_us = stagger;
-    static const int tall = [] { const char* e = getenv("GDT_C_TALL"); return e ? atoi(e) : 1; }();      // 0: the 2 x 2 wave layout
-    if (tall) {
-        if (!d.in_norm) return launch_c<0, 0, true>(d, stream);
-        if (d.in_res) {
-            if (d.in_out) return launch_c<7, 0, true>(d, stream);
-            return launch_c<3, 0, true>(d, stream);
-        }
-        return d.in_out ? launch_c<5, 0, true>(d, stream) : launch_c<1, 0, true>(d, stream);
-    }
     if (!d.in_norm) return launch_c<0>(d, stream);
     if (d.in_res) {
         if (d.in_out) return launch_c<7>(d, stream);
@@ -655,7 +631,7 @@ bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_HALO_C"); return e ? atoi(e) : 1; }();   // 0 off
     if (mode == 0 || !d.w_cfrag || !d.wmx_a || !d.wmx_b || !d.out || d.out_f32 || d.res || d.phase_cout || d.pool2 || d.pad_reflect) return false;
     const int cr = d.Cin >> 2;
-    if ((cr != 64 && cr != 128) || d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.CoutPad % 128 != 0 || d.Cout % 8 != 0) return false;
+    if ((cr != 64 && cr != 128) || d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.CoutPad % 256 != 0 || d.Cout % 8 != 0) return false;
     if (d.OH != (d.H - 1) / 2 + 1 || d.OW != (d.W - 1) / 2 + 1) return false;
     if ((d.in_res || d.in_out) && !d.in_norm) return false;
     if (d.stats && ((d.OH & 15) || (d.OW & 15))) return false;
@@ -663,21 +639,12 @@ bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
     const long tiles = (long)d.N * ((d.OW + 15) / 16) * ((d.OH + 15) / 16);
     const double useful = (double)d.OH * d.OW / ((double)((d.OH + 15) / 16 * 16) * ((d.OW + 15) / 16 * 16));
     static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 16; }();      // (below: the generic f16x3 kernels; batch 1-4 at 256^2 measured 2.09 vs 2.38 ms with the patch kernels on 16 tiles)
-    return tiles * (d.CoutPad % 256 == 0 ? d.CoutPad / 256 : d.CoutPad / 128) >= min_tiles && useful >= 0.85;
+    return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
 }
 
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
     d.dbg = c_dbg();
-    if (d.CoutPad % 256 != 0) {
-        if (!d.in_norm) return launch_c<0, 2, false, 128>(d, stream);
-        return d.in_out ? launch_c<5, 2, false, 128>(d, stream) : launch_c<1, 2, false, 128>(d, stream);
-    }
-    static const int tall = [] { const char* e = getenv("GDT_C_TALL_S2"); return e ? atoi(e) : 1; }();      // 0: the 2 x 2 wave layout
-    if (tall) {
-        if (!d.in_norm) return launch_c<0, 2, true>(d, stream);
-        return d.in_out ? launch_c<5, 2, true>(d, stream) : launch_c<1, 2, true>(d, stream);
-    }
     if (!d.in_norm) return launch_c<0, 2>(d, stream);
     return d.in_out ? launch_c<5, 2>(d, stream) : launch_c<1, 2>(d, stream);
 }

@@ -801,7 +801,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             // input pixel (2R + py, 2C + px); kernel row ky = 0 for (dy -1, py 1), 1 for (0, 0), 2 for (0, 1), none for (-1, 0); columns alike
             PackedPhase& sp = o.s2;
             sp.ntaps = 4; sp.TW = 2; sp.dy0 = -1; sp.dys = 1; sp.dx0 = -1; sp.dxs = 1; sp.Kpad = 16 * cin_pad;
-            o.s2_cout_pad = (cd.cout + 255) / 256 * 256;
+            o.s2_cout_pad = (cd.cout + 127) / 128 * 128;             // (128-column tiles for Cout <= 128: no padding columns to multiply)
             std::vector<float> wf((size_t)o.s2_cout_pad * sp.Kpad, 0.f);
             auto tap_of = [](int shift, int par) { return shift == 0 ? (par == 1 ? 0 : -1) : (par == 0 ? 1 : 2); };
             for (int co = 0; co < cd.cout; ++co)
