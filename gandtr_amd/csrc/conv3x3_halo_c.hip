@@ -367,8 +367,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         if (kk < 3) afr[i] = a_frag(i, ty, tx, kk + 1);
                         else if (t < NTAP - 1) afr[i] = a_frag(i, nty, ntx, 0);
                         if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all columns are re-loaded
-                            aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
-                            if (!(GDT_C_ABL & 2) && 2 * i < TN) {
+                            if (!(GDT_C_ABL & 64)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
+                            if (!(GDT_C_ABL & (2 | 128)) && 2 * i < TN) {
                                 if (ct_on(t_of(u), 2 * i)) load_bq(2 * i, tn_of(u), ks_of(u));
                                 if (ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
                             }
