@@ -59,6 +59,48 @@ def test_halo_c_conv3x3(cuda_device, norm, res, reflect):
         assert _rel(outs[taps[2]].double().cpu(), a) < 1e-5          # the write-back of the folded normalisation is plain fp32
 
 
+@pytest.mark.parametrize("kind", ["conv3x3", "stride2", "stride2_128", "transposed"])
+def test_halo_c_ragged_patches(cuda_device, kind):
+    """image sizes that are not multiples of the 16 x 16 patch (the checked epilogue body, halo rows beyond the image) on the
+    compensated kernels: 3x3 (1 x 4 wave layout), stride 2 (256- and 128-column tiles), transposed; no statistics consumer
+    (fused statistics need whole patches)"""
+    n, h, w = 6, 76, 92
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    if kind == "conv3x3":
+        cin, cout = 256, 256
+        t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+        wt, bias = _g(0, "w", (cout, cin, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
+        out = net.conv(t0, wt, bias, pad=1, reflect=False, relu=True)
+        ref_fn = lambda a: F.relu(F.conv2d(a, wt.double(), bias.double(), padding=1))
+    elif kind.startswith("stride2"):
+        cin, cout = (64, 128) if kind == "stride2_128" else (128, 256)
+        h, w = 2 * h, 2 * w                                         # ragged OUTPUT grid 76 x 92
+        t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+        wt, bias = _g(0, "w", (cout, cin, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
+        out = net.conv(t0, wt, bias, stride=2, pad=1)
+        ref_fn = lambda a: F.conv2d(a, wt.double(), bias.double(), stride=2, padding=1)
+    else:
+        cin, cout = 256, 128
+        t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
+        wt, bias = _g(0, "w", (cin, cout, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
+        out = net.conv(t0, wt, bias, stride=2, pad=1, transposed=True)
+        ref_fn = lambda a: F.conv_transpose2d(a, wt.double(), bias.double(), stride=2, padding=1, output_padding=1)
+    tap = net.output_nchw(out)
+    net.finalize()
+    x = synth.synth_input(5, (n, 3, h, w))
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    variant = [v for k, v, ms, fl in net.profile() if k == 1][-1]
+    assert variant in (970256, 980256, 990256), variant               # a compensated patch kernel ran the layer
+    a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
+    ref = ref_fn(a0)
+    got = outs[tap].double().cpu()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 2e-4
+
+
 @pytest.mark.parametrize("cin,cout,norm,res", [(256, 128, False, False), (256, 128, True, True), (128, 64, True, False)])
 def test_halo_c_transposed(cuda_device, cin, cout, norm, res):
     """ConvTranspose2d(k3, s2, p1, op1) on the compensated kernel's transposed form (four input shifts, sub-pixel scatter), with the
