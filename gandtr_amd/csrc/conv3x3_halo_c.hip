@@ -605,6 +605,17 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
     d.dbg = dbg;
     static const int stagger = [] { const char* e = getenv("GDT_C_STAGGER_US"); return e ? atoi(e) : 0; }();
     d.stagger_us = stagger;
+    // few patches (batch 1-4 at 256^2: 16-64 tiles for 256 CUs): 128-column tiles double the number of workgroups
+    static const int narrow_below = [] { const char* e = getenv("GDT_C_NARROW_BELOW"); return e ? atoi(e) : 192; }();
+    const long tiles256 = (long)d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH) * (d.CoutPad / 256);
+    if (tiles256 < narrow_below) {
+        if (!d.in_norm) return launch_c<0, 0, false, 128>(d, stream);
+        if (d.in_res) {
+            if (d.in_out) return launch_c<7, 0, false, 128>(d, stream);
+            return launch_c<3, 0, false, 128>(d, stream);
+        }
+        return d.in_out ? launch_c<5, 0, false, 128>(d, stream) : launch_c<1, 0, false, 128>(d, stream);
+    }
     static const int tall = [] { const char* e = getenv("GDT_C_TALL"); return e ? atoi(e) : 1; }();      // 0: the 2 x 2 wave layout
     if (tall) {
         if (!d.in_norm) return launch_c<0, 0, true>(d, stream);
