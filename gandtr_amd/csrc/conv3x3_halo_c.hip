@@ -136,10 +136,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
         int cbyte = (chunk * 8 + q) * 32;                            // byte offset of this piece's 8 channels within its pixel
         if (S2) {                                                     // virtual channel -> (sub-pixel parity, real channel)
-            const int vch = chunk * 64 + q * 8, cr = d.Cin >> 2;
-            const int par = vch / cr;                                 // (cr is a power of two >= 64: a chunk never straddles parities)
+            const int vch = chunk * 64 + q * 8, lcr = d.lc8 + 1;      // cr = Cin / 4 real channels = 2^lcr (a power of two >= 64:
+            const int par = vch >> lcr;                               //  a chunk never straddles parities; shifts, not a division)
             iy = 2 * iy + (par >> 1); ix = 2 * ix + (par & 1);
-            cbyte = (vch - par * cr) * 4;
+            cbyte = (vch & ((1 << lcr) - 1)) * 4;
         }
         int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
         int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
@@ -320,7 +320,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int c = 0; c < nchunks; ++c) {
+        // One 64-channel chunk.  S2M (stride-2 form): the shifts with a non-zero weight block for the chunk's sub-pixel parity, a
+        // COMPILE-TIME constant per instantiation of the body (dy = -1 needs odd input rows, dx = -1 odd columns: parity 0 -> shift 3
+        // only, 1 -> 2 3, 2 -> 1 3, 3 -> all) -- the chunk loop below runs the four parities one after the other, so an inactive
+        // tap costs neither MFMAs nor fragment / weight loads nor branches (with run-time masks: ~300 branches per chunk, and the
+        // scheduler could not interleave the halo staging across them).
+        auto chunk_body = [&](const int c, auto mask_tag) {
+            constexpr unsigned S2M = decltype(mask_tag)::value;      // 0: run-time mask (256-column stride-2 tiles: four bodies spill 130-180 registers there)
+            unsigned s2_rt = 0xFu;
+            if (S2 && S2M == 0) { const int par = (c * 64) >> (d.lc8 + 1); s2_rt = (par & 2 ? 0xFu : 0xCu) & (par & 1 ? 0xFu : 0xAu); }
+            auto s2_on = [&](int t) -> bool { return !S2 || (((S2M ? S2M : s2_rt) >> t) & 1u) != 0; };      // MFMAs of tap t
+            auto s2_ld = [](int t) -> bool { return !S2 || S2M == 0 || ((S2M >> t) & 1u) != 0; };              // its loads (static masks only)
             const bool last = c + 1 == nchunks;
             const bool to_next = last && nxt.valid;
             const TileAt sta = to_next ? nxt : cur;
@@ -334,9 +344,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             auto ct_on = [](int t, int j) -> bool { return !CT || !GDT_C_CT_SKIP || (((0xF531u >> (4 * j)) >> t) & 1u) != 0; };
             // tap of substep u (u >= SLOTS: the first substeps of the chunk staged now)
             auto t_of = [](int u) -> int { return u < SLOTS ? (u >> 2) : ((u - SLOTS) >> 2); };
-            // (S2) shifts with a non-zero weight block for this chunk's sub-pixel parity: dy = -1 (ty 0) needs odd input rows, dx = -1 odd columns
-            unsigned s2_mask = 0xFu;
-            if (S2) { const int par = (c * 64) / (d.Cin >> 2); s2_mask = (par & 2 ? 0xFu : 0xCu) & (par & 1 ? 0xFu : 0xAu); }
+            // (within the chunk: u < SLOTS; slices of the next chunk are always fetched -- its parity is another instantiation's business)
+            auto s2_on_u = [&](int u) -> bool { return u >= SLOTS || s2_ld(u >> 2); };
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 const int ty = SHIFT ? (t >> 1) : t / 3, tx = SHIFT ? (t & 1) : t - ty * 3;
@@ -359,16 +368,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         // for the next substep (single-buffered: 16 registers instead of 32)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            if (!(GDT_C_ABL & 8) && ct_on(t, j) && (!S2 || ((s2_mask >> t) & 1u)))
+                            if (!(GDT_C_ABL & 8) && ct_on(t, j) && s2_on(t))
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
-                        if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
-                        if (kk < 3) afr[i] = a_frag(i, ty, tx, kk + 1);
-                        else if (t < NTAP - 1) afr[i] = a_frag(i, nty, ntx, 0);
+                        if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i) && s2_on_u(u + RING - 1)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
+                        if (kk < 3) { if (s2_ld(t)) afr[i] = a_frag(i, ty, tx, kk + 1); }
+                        else if (t < NTAP - 1) { if (s2_ld(t + 1)) afr[i] = a_frag(i, nty, ntx, 0); }
                         if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all columns are re-loaded
-                            if (!(GDT_C_ABL & 64)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
-                            if (!(GDT_C_ABL & (2 | 128)) && 2 * i < TN) {
+                            if (!(GDT_C_ABL & 64) && s2_ld(t)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
+                            if (!(GDT_C_ABL & (2 | 128)) && 2 * i < TN && s2_ld(t)) {
                                 if (ct_on(t_of(u), 2 * i)) load_bq(2 * i, tn_of(u), ks_of(u));
                                 if (ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
                             }
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                if (ct_on(t, j) && (!S2 || ((s2_mask >> t) & 1u))) {
+                                if (ct_on(t, j) && s2_on(t)) {
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
                                 }
                         }
@@ -422,6 +431,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                 for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
             }
+        };
+        if (!S2) {
+            for (int c = 0; c < nchunks; ++c) chunk_body(c, std::integral_constant<unsigned, 0xFu>());
+        } else if (BN != 128) {
+            for (int c = 0; c < nchunks; ++c) chunk_body(c, std::integral_constant<unsigned, 0u>());
+        } else {
+            const int cpp = nchunks >> 2;                   // chunks per sub-pixel parity (1 or 2)
+            for (int cc = 0; cc < cpp; ++cc) chunk_body(cc, std::integral_constant<unsigned, 0x8u>());
+            for (int cc = 0; cc < cpp; ++cc) chunk_body(cpp + cc, std::integral_constant<unsigned, 0xCu>());
+            for (int cc = 0; cc < cpp; ++cc) chunk_body(2 * cpp + cc, std::integral_constant<unsigned, 0xAu>());
+            for (int cc = 0; cc < cpp; ++cc) chunk_body(3 * cpp + cc, std::integral_constant<unsigned, 0xFu>());
         }
 
         // ------------------------------------------------------------ tile end: all waves are done with the last halo stage and
