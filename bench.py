@@ -414,6 +414,14 @@ def main():
         dt2 = timed(step, a.steps, a.warmup, dev, distributed)
         r_dps = n_total * a.steps / dt2
         roof2 = conv_roofline(emb, xe) if rank == 0 else None
+        if roof2 is not None and roof2.get("kernel") == "conv1x1_rb_kernel":
+            # the Bottleneck 1x1 convs are HBM-bound, not MFMA-bound: algorithmic bytes of the 58 launches of one forward (fp16 in + out
+            # + residual, weights negligible: 1.274 GB per 1024^2 image over the 64 launches) over their summed launch time
+            bytes_1x1 = 1.274e9 * a.r101_batch
+            t_1x1 = roof2["avg_launch_ms"] * 1e-3 * roof2["launches_per_step"]
+            roof2["hbm_view"] = {"bound": "hbm", "achieved": round(bytes_1x1 / t_1x1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(bytes_1x1 / t_1x1 / 8e12, 4),
+                                 "note": "algorithmic bytes of every launch of this kernel in one forward / their summed time"}
         secondary = {"metric": "descriptors/sec GeM-ResNet101 single-scale @1024x1024", "value": round(r_dps, 2),
                      "unit": "descriptors/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3), "dtype": "f16",
                      "config": {"workload": "gem_resnet101 forward + GeM + L2N (+ RCCL all-gather when N>1), synthetic 3x1024x1024",
