@@ -26,7 +26,10 @@ class Compose:
         self.wrappers = wrappers
         self.device = device
 
-    def __call__(self, tensor, inference, outputmodel=None, tensor_params=None):
+    def __call__(self, tensor, inference, outputmodel=None, tensor_params=None, fold_input=False):
+        """``fold_input``: the caller guarantees that ``inference`` hands the wrapper-processed tensor straight to ``outputmodel``
+        (SingleNetwork.forward does; a SequentialNetwork, whose hoisted wrappers act on the CHAIN input while ``outputmodel`` is the
+        last member, never does) -- only then may trailing per-channel input wrappers run inside the model's input pack."""
         tensor_params = {} if tensor_params is None else tensor_params
         if not self.wrappers:
             if isinstance(tensor, torch.Tensor):
@@ -34,7 +37,7 @@ class Compose:
             return inference(tensor, **tensor_params)
         if outputmodel is None:
             outputmodel = inference
-        active, folded = self._fold_input_wrappers(outputmodel)
+        active, folded = self._fold_input_wrappers(outputmodel) if fold_input else (self.wrappers, None)
         metas = []
         for w in active:
             tensor, meta = w.preprocess(tensor, outputmodel)
@@ -42,11 +45,7 @@ class Compose:
         if folded is None:
             tensor = inference(tensors.to_device(tensor, self.device), **tensor_params)
         else:                               # the trailing per-channel input wrappers run inside the model's HIP input-pack kernel
-            previous, outputmodel.input_transform = outputmodel.input_transform, folded
-            try:
-                tensor = inference(tensors.to_device(tensor, self.device), **tensor_params)
-            finally:
-                outputmodel.input_transform = previous
+            tensor = inference(tensors.to_device(tensor, self.device), input_transform=folded, **tensor_params)
         for w, meta in reversed(list(zip(active, metas))):
             tensor = w.postprocess(tensor, outputmodel, meta)
         return tensor
@@ -61,8 +60,13 @@ class Compose:
         dev = getattr(outputmodel, "_hip_device", None)
         if dev is None or dev().type != "cuda":
             return self.wrappers, None
+        nch = (getattr(outputmodel, "meta", None) or {}).get("in_channels")
+
+        def foldable(w):
+            tr = w.input_transform()
+            return tr is not None and all(len(a) == nch for a in tr[1:])
         cut = len(self.wrappers)
-        while cut > 0 and self.wrappers[cut - 1].input_transform() is not None:
+        while cut > 0 and foldable(self.wrappers[cut - 1]):
             cut -= 1
         if cut == len(self.wrappers):
             return self.wrappers, None
@@ -142,6 +146,13 @@ class MeanStdPost(Wrapper):
 
 class MeanStdPre(MeanStdPost):
     def input_transform(self):
+        """per-channel form only when all four of mean / std (in, out) are flat lists of one length (``mean2tensor`` also accepts
+        scalars-as-tensors and full tensors, which broadcast differently: those run on the host as the reference does)"""
+        flat = [x for pair in self.raw for x in pair]
+        if not all(isinstance(x, (list, tuple)) and x and all(isinstance(v, (int, float)) for v in x) for x in flat):
+            return None
+        if len({len(x) for x in flat}) != 1:
+            return None
         scale, shift = self.affine()
         return ("affine", scale, shift)
 

@@ -27,20 +27,21 @@ class HedInterpolation(HipBacked, nn.Module):
         for i, chans in enumerate(BLOCKS):
             setattr(self, "score%d" % (i + 1), nn.Conv2d(chans[-1], 1, kernel_size=1))
         self.fusion = nn.Sequential(nn.Conv2d(5, 1, kernel_size=1))
-        # per-channel input transform (perm, scale, shift) applied inside the HIP input-pack kernel; set for the duration of a call by
-        # Compose when the trailing wrappers are RgbToBgrPre / MeanStdPre (components/data/wrapper.py, _fold_input_wrappers)
-        self.input_transform = None
         if pretrained:
             from ....tools.utils import fs_open
             with fs_open(pretrained) as handle:
                 self.load_state_dict(torch.load(handle, map_location="cpu"))
 
-    def forward(self, x, no_sigmoid=False):
+    def forward(self, x, no_sigmoid=False, input_transform=None):
+        """``input_transform``: per-channel (perm, scale, shift) applied inside the HIP input-pack kernel, passed per call by Compose
+        when the trailing wrappers are RgbToBgrPre / MeanStdPre (components/data/wrapper.py, _fold_input_wrappers)"""
+        if input_transform is not None and self._hip_device().type != "cuda":
+            raise ValueError("input_transform is a HIP-path argument")
         if self._hip_device().type == "cuda":
             from .... import engine
             self._hip_check_inference()
             prec = self._hip_precision()
-            tr = self.input_transform
+            tr = input_transform
             net = self._hip_net(("hed", bool(no_sigmoid), prec, tr),
                                 lambda sd, dev: engine.build_hed(sd, dev, sigmoid=not no_sigmoid, precision=prec, perm=None if tr is None else list(tr[0]),
                                                                  in_affine=None if tr is None else (list(tr[1]), list(tr[2]))))

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         asm volatile("" : "+v"(lr));
         const int h = min(r * RPR + lr, HROWS_PAD - 1);
         const int hy = (h * (SHIFT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;
-        const int q = (lane & 7) ^ ((hx >> 1) & 7);
+        const int q = lane & 7;          // a lane always fetches the same 8-channel group of its pixel; the swizzle is applied at the LDS write
         int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
         int cbyte = (chunk * 8 + q) * 32;                            // byte offset of this piece's 8 channels within its pixel
         if (S2) {                                                     // virtual channel -> (sub-pixel parity, real channel)
@@ -160,17 +160,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             *(float4*)(nlds + slot * 512 + i * 4) = make_float4(v.y, -v.x * v.y, v.w, -v.z * v.w);
         }
     };
-    auto store_piece = [&](int slot, int stage_off, int r, const Pend& p) {
+    // (scale, shift) of the lane's 8 channels in the chunk being staged: a lane's channel group is the same for every piece of a chunk,
+    // so the factors are fetched from the LDS table once per chunk, not per piece (per piece: four dependent LDS reads, each behind an
+    // `s_waitcnt lgkmcnt(0)` that also drained the fragment reads in flight)
+    float4 nf[4];
+    auto load_nf = [&](int slot, int chunk) {
+        if (!NORM) return;
+        const int cq = S2 ? ((chunk * 64 + (lane & 7) * 8) & ((1 << (d.lc8 + 1)) - 1)) >> 3 : chunk * 8 + (lane & 7);    // the (real) 8-channel group
+        const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nf[k] = np4[k];
+    };
+    auto store_piece = [&](int stage_off, int r, const Pend& p) {
         const int row = min(r * RPR + lrow, HROWS_PAD - 1);
         const int phy = (row * (SHIFT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
         float a[8] = {p.r0.x, p.r0.y, p.r0.z, p.r0.w, p.r1.x, p.r1.y, p.r1.z, p.r1.w};
         if (NORM) {
-            const int cq = (p.goff >> 5) & ((1 << (d.lc8 - (S2 ? 2 : 0))) - 1);    // the piece's (real) 8-channel group
-            const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
             const float lo = d.in_relu ? 0.f : -3.0e38f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 v = np4[k];
+                const float4 v = nf[k];
                 a[2 * k] = fmaxf(fmaf(a[2 * k], v.x, v.y), lo);
                 a[2 * k + 1] = fmaxf(fmaf(a[2 * k + 1], v.z, v.w), lo);
             }
@@ -204,10 +213,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
         const f16x8 o = __builtin_bit_cast(f16x8, ov);
-        *(f16x8*)(smem + stage_off + row * ROWB + ((lane & 7) << 4)) = o;
+        *(f16x8*)(smem + stage_off + row * ROWB + (((lane & 7) ^ ((phx >> 1) & 7)) << 4)) = o;      // source chunk q at position q ^ key (a_frag)
         // fp4 plane: this thread holds source chunk q (channels 8q .. 8q+7): 32-channel block b = q >> 2, dword q & 3;
         // 16-byte position (2b + {lo 0, hi 1}) ^ key, key = conflict-free swizzle of the fragment reads (see a_qfrag)
-        const int q = (lane & 7) ^ ((phx >> 1) & 7);
+        const int q = lane & 7;
         const int key = SHIFT ? ((phy + 2 * (phx >> 2)) & 3) : ((phx >> 1) & 3);
         const int qo = stage_off + A_BYTES + row * QROWB + ((((q >> 2) << 1) ^ key) << 4) + ((q & 3) << 2);
         *(unsigned*)(smem + qo) = qlo;
@@ -217,8 +226,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // ---- weights, streamed L2 -> registers in MFMA fragment order.  Grouped layouts (net.hip pack_mx): the four 32-channel
     // fragments a wave needs for one k-substep are contiguous, so one scalar base + 32-bit lane offset + an immediate (j * 1 KB)
     // addresses each of them (the scalar-base form of global_load: no 64-bit vector address arithmetic):
-    //   w_cfrag [cout/128][K/16][4][64 lanes][16 B]      wmx_a [cout/128][K/32][4][64][16 B]      wmx_b [cout/128][K/32][4][64][12 B]
-    // (wmx_a + the first 8 bytes of wmx_b = the lane's 32 e2m3 values, the last 4 bytes of wmx_b = its E8M0 block scale).
+    //   w_cfrag [cout/128][K/16][4][64 lanes][16 B]    wmx_a [cout/128][K/32][4][64][16 B]    wmx_b [..][64][8 B]    wmx_s [..][64][4 B]
+    // (a lane's 32 e2m3 values = 16 bytes of wmx_a + 8 of wmx_b, fetched by a dwordx4 and a dwordx2 load INTO the MFMA's 6-register
+    // operand tuple; its E8M0 block scale = a dword of wmx_s.  Three arrays because (a) any load whose register tuple is not exactly a
+    // sub-tuple of that operand -- the earlier 16 + 12-byte split with the scale behind the values, or two dwordx4 into an 8-tuple --
+    // makes the compiler land it in scratch registers and copy it over behind an `s_waitcnt vmcnt(0..4)` at the top of the NEXT
+    // substep: one exposed L2 latency per 32 k-values; (b) adjacent loads from one base are merged back into such a load by the
+    // load vectoriser; (c) every array must stay contiguous over the 64 lanes of a fragment: 32-byte per-lane records made each of the
+    // three loads touch 16 cache lines instead of 8 + 4 + 2 and the L1 line rate, not the bytes, is what the weight stream costs.)
     // One wave per SIMD issues in order, so no load may wait on the MFMAs of its own substep: the fp16 fragments live in a ring of
     // RING substep slices and substep u re-loads the slot that substep u - 1 has just finished with (slice u + RING - 1); the MX
     // fragments of group g (32 k-values, MFMAs at the end of substep 2g + 1) are re-loaded with group g + 1 early in substep 2g + 2.
@@ -228,15 +243,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     static_assert(TN == 4 || TN == 2, "the weight streams are grouped per 128 output channels");
     const int wgrp_of_wave = (wn * WTN) >> 7, wblk = ((wn * WTN) >> 5) & 3;      // the wave's 128-column weight group within the tile, its first 32-column block in it
     const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
-    typedef int v3i __attribute__((ext_vector_type(3)));
     f16x8 b[RING][TN];
-    v8i bq[TN];             // registers 0-5: the lane's 32 e2m3 values, register 6: its block scale (loaded in place: dwordx4 + dwordx3)
+    typedef int v6i __attribute__((ext_vector_type(6)));
+    v6i bq[TN];             // the lane's 32 e2m3 values: the MFMA's 6-register operand tuple, loaded in place (dwordx4 + dwordx2)
+    int bqs[TN];            // its E8M0 block scale
     auto lane_bytes = [&](int per_lane) -> unsigned {     // (opaque: keeps the zero-extension next to its load, which is what lets the
         unsigned v = lane * per_lane;                      //  compiler pick the scalar-base addressing form)
         asm volatile("" : "+v"(v));
         return v;
     };
-    unsigned lo16 = lane_bytes(16), lo12 = lane_bytes(12);        // (refreshed at the top of every chunk body)
+    unsigned lo16 = lane_bytes(16), lo8 = lane_bytes(8), lo4 = lane_bytes(4);        // (refreshed at the top of every chunk body)
     auto load_b = [&](int rs, int j, int tile_n, long ks) {       // ks: uniform k-substep index (16 k-values each)
         const char* wb = (const char*)d.w_cfrag + ((long)(tile_n * (BN / 128) + wgrp_of_wave) * nks + ks) * 4096;
         b[rs][j] = *(const f16x8*)(wb + lo16 + (wblk + j) * 1024);
@@ -244,9 +260,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     auto load_bq = [&](int j, int tile_n, long ks) {     // MX fragment j of the 32-k group starting at substep ks (even)
         const long f0 = (long)(tile_n * (BN / 128) + wgrp_of_wave) * nms + (ks >> 1);
         const v4i qa = *(const v4i*)((const char*)d.wmx_a + f0 * 4096 + lo16 + (wblk + j) * 1024);
-        const v3i qb = *(const v3i*)((const char*)d.wmx_b + f0 * 3072 + lo12 + (wblk + j) * 768);
-        bq[j] = __builtin_shufflevector(__builtin_shufflevector(qa, qa, 0, 1, 2, 3, -1, -1, -1, -1),
-                                             __builtin_shufflevector(qb, qb, 0, 1, 2, -1, -1, -1, -1, -1), 0, 1, 2, 3, 8, 9, 10, -1);
+        const v2i qb = *(const v2i*)((const char*)d.wmx_b + f0 * 2048 + lo8 + (wblk + j) * 512);
+        bq[j] = __builtin_shufflevector(__builtin_shufflevector(qa, qa, 0, 1, 2, 3, -1, -1), __builtin_shufflevector(qb, qb, 0, 1, -1, -1, -1, -1), 0, 1, 2, 3, 6, 7);
+        bqs[j] = *(const int*)((const char*)d.wmx_s + f0 * 1024 + lo4 + (wblk + j) * 256);
     };
 
     // A fragment addresses (see conv3x3_halo_rb.hip); fp4 plane: per-lane base per tap column (+ tap row for CT) with the swizzle key
@@ -296,8 +312,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         stage_norm(cur, 0);
         __syncthreads();
     }
+    load_nf(0, 0);
 #pragma unroll
-    for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
+    for (int r = 0; r < NR; ++r) store_piece(0, r, load_piece(cur, 0, r));
     __syncthreads();
     Pend pend[DEPTH];
 #pragma unroll
@@ -336,7 +353,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             const TileAt sta = to_next ? nxt : cur;
             const int sc = last ? 0 : c + 1, sslot = to_next ? slot ^ 1 : slot;
             if (NORM && nxt.valid && c == nchunks - 2) stage_norm(nxt, slot ^ 1);
-            lo16 = lane_bytes(16); lo12 = lane_bytes(12);
+            load_nf(sslot, sc);                 // (the table of the next tile was written during the previous chunk, a barrier ago)
+            lo16 = lane_bytes(16); lo8 = lane_bytes(8); lo4 = lane_bytes(4);
             // (CT) which input shifts t have a non-zero weight block for column block j of this wave (gdt_ctf_column: 64-column
             // slices pair a cheap phase with an expensive one)
             // -- with gdt_ctc_column() column block j of EVERY wave is sub-pixel phase j of 32 output channels: the masks are
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     const int u = t * 4 + kk, cu = kk & 1;
                     if (!(GDT_C_ABL & 1) && u % SPR == 0) {      // halo of the next chunk: one loader round in flight, written SPR substeps after its load
                         const int r = u / SPR;
-                        if (r >= DEPTH && r - DEPTH < NR) store_piece(sslot, STAGE_BYTES - so, r - DEPTH, pend[r % DEPTH]);
+                        if (r >= DEPTH && r - DEPTH < NR) store_piece(STAGE_BYTES - so, r - DEPTH, pend[r % DEPTH]);
                         if (r < NR) pend[r % DEPTH] = load_piece(sta, sc, r);
                     }
 #pragma unroll
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
                                 if (ct_on(t, j) && s2_on(t)) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bq[j], av, acc[i][j], 2, 4, 0, bq[j][6], 0, a_scale);
+                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_shufflevector(bq[j], bq[j], 0, 1, 2, 3, 4, 5, -1, -1), av, acc[i][j], 2, 4, 0, bqs[j], 0, a_scale);
                                 }
                         }
                     }

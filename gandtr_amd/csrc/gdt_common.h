@@ -74,9 +74,8 @@ struct ConvLaunch {
     int stats_tile_base;          // tile index offset for this launch in the stats slab (ConvTranspose phases)
     int pool2;                    // 1: MaxPool2d(2, 2) fused into the epilogue of the patch kernels; `out` is the pooled [N][H/2][W/2][Cout] tensor
     // "f16c" precision mode (conv3x3_halo_c.hip): block-scaled correction operands of the weights in MFMA fragment order --
-    // wmx_a [CoutPad/128][Kpad/32][4][64 lanes][16 B] and wmx_b [..][12 B]: 32 e2m3 values per lane (24 bytes) + its E8M0 block scale (1 dword) (lanes 0-31: fp16(w) of output channel
-    // lane, lanes 32-63: w - fp16(w), same 32 k-values); wmx_s [CoutPad/128][Kpad/64][4][64] dwords: E8M0 block scales (byte 0 / 1 = first /
-    // second 32-k block).  Activation side: a_lo is stored as fp4(a_lo * 2^c_lo_exp), a_hi as fp4(a_hi * 2^-c_hi_exp).
+    // wmx_a [CoutPad/128][Kpad/32][4][64 lanes][16 B] + wmx_b [..][64][8 B]: per lane 32 e2m3 values (24 bytes); wmx_s [..][64] dwords: its E8M0
+    // block scale (lanes 0-31: fp16(w) of output channel lane, lanes 32-63: w - fp16(w), same 32 k-values).  Activation side: a_lo is stored as fp4(a_lo * 2^c_lo_exp), a_hi as fp4(a_hi * 2^-c_hi_exp).
     const f16* w_frag2;           // conv_stem.hip, f16c form: the weight residuals W2 = [w - fp16(w), 0 ..] in the stem fragment order
     const void* w_cfrag;          // fp16 weights grouped per 128 output channels: [CoutPad/128][Kpad/16][4][64 lanes][8 halves] (wmx_* grouped alike)
     const void* wmx_a; const void* wmx_b; const void* wmx_s;

@@ -88,6 +88,20 @@ std::map<AxisKey, DevCoeffs> g_cache;
 
 unsigned bits_of(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
+// Eviction happens ONLY here, at the start of a top-level call and before it has taken any table pointer: a call that is being
+// assembled (the batched entry keeps up to 2n table pointers in its descriptor array before the first launch) must never see a table
+// freed under it.  `needed` = the number of tables the call may add.  The device is synchronised first, so launches of earlier
+// calls that still read the old tables have completed.
+int cache_begin_call(size_t needed) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    const size_t limit = std::max<size_t>(256, 2 * needed);
+    if (g_cache.size() + needed <= limit) return GDT_OK;
+    GDT_CHECK_HIP(hipDeviceSynchronize());
+    for (auto& e : g_cache) { (void)hipFree(e.second.bounds); (void)hipFree(e.second.kk); }
+    g_cache.clear();
+    return GDT_OK;
+}
+
 int axis_coeffs(int in_size, float in0, float in1, int out_size, hipStream_t stream, DevCoeffs& out) {
     int dev = 0;
     GDT_CHECK_HIP(hipGetDevice(&dev));
@@ -95,11 +109,6 @@ int axis_coeffs(int in_size, float in0, float in1, int out_size, hipStream_t str
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { out = it->second; return GDT_OK; }
-    if (g_cache.size() >= 256) {                                     // bounded: drop everything (tables are tiny, rebuilt on demand)
-        GDT_CHECK_HIP(hipDeviceSynchronize());
-        for (auto& e : g_cache) { (void)hipFree(e.second.bounds); (void)hipFree(e.second.kk); }
-        g_cache.clear();
-    }
     Coeffs c;
     precompute_coeffs(in_size, in0, in1, out_size, c);
     DevCoeffs d;
@@ -383,7 +392,9 @@ int run_ingest(const unsigned char* src, int h, int w, int fx, int fy, const flo
     const bool need_h = out_w != cw || box[0] != 0.f || box[2] != (float)out_w;
     const bool need_v = out_h != ch || box[1] != 0.f || box[3] != (float)out_h;
     DevCoeffs kh, kv;
-    int rc = axis_coeffs(ch, box[1], box[3], out_h, stream, kv);
+    int rc = cache_begin_call(2);
+    if (rc != GDT_OK) return rc;
+    rc = axis_coeffs(ch, box[1], box[3], out_h, stream, kv);
     if (rc != GDT_OK) return rc;
     int first = 0, rows = ch;
     if (need_v) { first = kv.first; rows = kv.last - kv.first; }
@@ -468,6 +479,10 @@ int run_ingest_batch(const gdt_ingest_item* items, int n, int c, const float* me
     int max_rw = 1, max_rh = 1, max_ow = 1, max_rows = 1, max_oh = 1;
     bool any_reduce = false, any_h = false;
     std::vector<float> boxes((size_t)n * 4);
+    {
+        const int rc0 = cache_begin_call(2 * (size_t)n);
+        if (rc0 != GDT_OK) return rc0;
+    }
     for (int i = 0; i < n; ++i) {
         const gdt_ingest_item& it = items[i];
         const IngestPlan& p = bp.plans[i];

@@ -532,12 +532,14 @@ int quant_e2m3(float x) {
 // Block-scaled correction operands of a packed weight matrix wf [cout_pad][Kpad] (fp32, BatchNorm folded) in MFMA fragment order:
 // per (32-channel block cb, 32-k block ms, lane): lanes 0-31 hold fp16(w), lanes 32-63 hold w - fp16(w) of output channel cb*32 + (lane & 31),
 // each as 32 e2m3 values of  value * 2^-e  with the block's own E8M0 exponent byte 127 + e (largest magnitude of the block mapped into
-// (3.75, 7.5]).  Element i sits at bit 6i of the lane's 24 bytes; the first 16 go to `a`, the last 8 to `b`.
+// (3.75, 7.5]).  Element i sits at bit 6i of the lane's 24 bytes: the first 16 go to `a`, the last 8 to `b`, the E8M0 scale (a dword) to `sc` -- three
+// arrays, each contiguous over the 64 lanes of a fragment, so that the kernel's dwordx4 / dwordx2 / dword loads touch 8 + 4 + 2 cache lines per
+// fragment and land exactly in the MFMA's operand registers (conv3x3_halo_c.hip load_bq).
 // Layouts are grouped per 128 output channels (see ConvLaunch::w_cfrag): index = ((group * steps + step) * 4 + block in group) * 64 + lane.
 void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<unsigned char>& a, std::vector<unsigned char>& b,
              std::vector<unsigned>& sc, std::vector<f16>& wc) {
     const int ncb = cout_pad / 32, nms = Kpad / 32, nks = Kpad / 16;
-    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 12, 0); sc.clear();
+    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 8, 0); sc.assign((size_t)ncb * nms * 64, 0);
     wc.assign((size_t)cout_pad * Kpad, (f16)0.f);
     for (int cb = 0; cb < ncb; ++cb)
         for (int ks = 0; ks < nks; ++ks)
@@ -567,8 +569,8 @@ void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<u
                     if ((bit & 7) > 2) bytes[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
                 }
                 const size_t fi = (((size_t)(cb >> 2) * nms + ms) * 4 + (cb & 3)) * 64 + ln;
-                const unsigned scale = (unsigned)(127 + e);           // E8M0 block scale rides behind the lane's data
-                memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 12, bytes + 16, 8); memcpy(b.data() + fi * 12 + 8, &scale, 4);
+                const unsigned scale = (unsigned)(127 + e);           // E8M0 block scale
+                memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 8, bytes + 16, 8); sc[fi] = scale;
             }
 }
 
@@ -697,7 +699,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             ph.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
             ph.wmx_a_off = net->blob_append(ma.data(), ma.size());
             ph.wmx_b_off = net->blob_append(mb.data(), mb.size());
-            ph.wmx_s_off = ph.wmx_b_off;
+            ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
             ph.has_mx = true;
         }
         if (!net->precision && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip
@@ -818,7 +820,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             sp.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
             sp.wmx_a_off = net->blob_append(ma.data(), ma.size());
             sp.wmx_b_off = net->blob_append(mb.data(), mb.size());
-            sp.wmx_s_off = sp.wmx_b_off;
+            sp.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
             sp.has_mx = true;
             if (has_shift) {
                 std::vector<float> bp(o.s2_cout_pad, 0.f);
@@ -873,7 +875,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 cf.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
                 cf.wmx_a_off = net->blob_append(ma.data(), ma.size());
                 cf.wmx_b_off = net->blob_append(mb.data(), mb.size());
-                cf.wmx_s_off = cf.wmx_b_off;
+                cf.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
                 cf.has_mx = true;
             }
             std::vector<f16> pf(net->precision ? 0 : pk.size());
@@ -1130,7 +1132,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.stats_tile_base = 0;
                     int variant = 960256;
                     if (net->precision == 2) {
-                        d.w_cfrag = net->dev_blob + o.ctf.wc_off; d.wmx_a = net->dev_blob + o.ctf.wmx_a_off; d.wmx_b = d.wmx_s = net->dev_blob + o.ctf.wmx_b_off;
+                        d.w_cfrag = net->dev_blob + o.ctf.wc_off; d.wmx_a = net->dev_blob + o.ctf.wmx_a_off; d.wmx_b = net->dev_blob + o.ctf.wmx_b_off; d.wmx_s = net->dev_blob + o.ctf.wmx_s_off;
                         d.c_lo_exp = 12; d.c_hi_exp = 0;
                         variant = 980256;
                         rc = gdt_launch_conv_halo_c_ct(d, st);
@@ -1143,7 +1145,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     s2_geometry(net, o, n, ti, d);
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.s2_bias_off) : nullptr;
                     d.out = tptr(o.out); d.out_f32 = nullptr; d.w = nullptr; d.w_lo = nullptr; d.w_frag = nullptr;
-                    d.w_cfrag = net->dev_blob + o.s2.wc_off; d.wmx_a = net->dev_blob + o.s2.wmx_a_off; d.wmx_b = d.wmx_s = net->dev_blob + o.s2.wmx_b_off;
+                    d.w_cfrag = net->dev_blob + o.s2.wc_off; d.wmx_a = net->dev_blob + o.s2.wmx_a_off; d.wmx_b = net->dev_blob + o.s2.wmx_b_off; d.wmx_s = net->dev_blob + o.s2.wmx_s_off;
                     d.c_lo_exp = 12; d.c_hi_exp = 0;
                     d.stats_tile_base = 0;
                     rc = gdt_launch_conv_halo_c_s2(d, st);

@@ -127,7 +127,7 @@ class SingleNetwork(Network):
     # ---- call path
     def forward(self, image, **params):
         chain = self.wrappers[self.stage]
-        return chain(image, self.forward_batch, outputmodel=self.model, tensor_params=params)
+        return chain(image, self.forward_batch, outputmodel=self.model, tensor_params=params, fold_input=True)
 
     def forward_batch(self, images, **params):
         if images is None:

@@ -248,10 +248,10 @@ def test_gem_l2n_golden(cuda_device):
 
 
 def test_validate_stage_on_gpu(cuda_device, tmp_path):
-    """mdir.stages.validate.validate on the device: batch-1 descriptor extraction (HIP embedder) and device-side ranking agree with
+    """the validate stage's arithmetic on the device: descriptor extraction (HIP embedder, equal sizes batched) and device-side ranking agree with
     the reference's two numpy lines on the same descriptors (cirscore.py:71-73)"""
     import copy
-    from gandtr_amd.stages.validate import validate, extract_vectors
+    from gandtr_amd.stages.validate import rank_images, extract_vectors
     import gandtr_amd.learning as L
     emb = {"type": "SingleNetwork",
            "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
@@ -263,10 +263,10 @@ def test_validate_stage_on_gpu(cuda_device, tmp_path):
     net.model.load_state_dict(synth.vgg16_state(0))                 # seeded weights (the reference leaves them unseeded)
     ck = tmp_path / "vgg.pth"
     torch.save(net.state_dict()["net"], ck)
-    params = {"network": {"path": str(ck), "runtime": copy.deepcopy(emb["runtime"])}, "validation": {}, "data": {}}
+    params = {"network": {"path": str(ck), "runtime": copy.deepcopy(emb["runtime"])}}
     db = [synth.synth_input(40 + i, (3, 96, 128 - 16 * (i % 3))) for i in range(12)]
     qs = [db[7] + 0.01 * synth.synth_input(50, db[7].shape), db[2]]
-    meta, ranks, scores = validate(copy.deepcopy(params), (db, qs))
+    meta, ranks, scores = rank_images(copy.deepcopy(params), (db, qs))
     assert ranks.shape == (12, 2) and scores.shape == (12, 2) and ranks[0, 1] == 2 and abs(scores[2, 1] - 1.0) < 1e-4
     net = L.load_network(copy.deepcopy(params["network"]), cuda_device).eval()
     vecs = extract_vectors(net, db, cuda_device)

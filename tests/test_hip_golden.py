@@ -113,7 +113,7 @@ def test_hed_with_wrappers_on_gpu(cuda_device, monkeypatch):
     assert float((out.cpu() - torch.from_numpy(g["out"])).abs().max()) < 1e-3
     keys = [k for k in net.model._hip_cache if isinstance(k, tuple) and k[0] == "hed"]
     assert keys and keys[0][3] is not None and keys[0][3][0] == (2, 1, 0)
-    assert net.model.input_transform is None                                    # restored after the call
+    assert not hasattr(net.model, "input_transform")                            # a call argument, never module state
 
 
 def test_chain_config5_on_gpu(cuda_device):

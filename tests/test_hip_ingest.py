@@ -128,6 +128,23 @@ def test_resize_many_matches_resize(cuda_device):
         ingest.resize_many([imgs[0], gray[0]], [plans[0], gplans[0]])                 # mixed channel counts
 
 
+def test_resize_many_across_the_coefficient_cache_limit(cuda_device):
+    """The device-resident coefficient tables are evicted only between calls: a batched call with more distinct geometries than the
+    cache holds (256 tables; 150 images of distinct sizes need up to 300) must still hand every item live tables -- bitwise equal
+    to the per-image call, which is evaluated AFTER the batch so that the batch ran on a cache pre-filled by other geometries."""
+    rng = np.random.default_rng(11)
+    warm = [torch.from_numpy(rng.integers(0, 256, (40 + i, 53 + 2 * i, 3)).astype(np.uint8)).to(cuda_device) for i in range(120)]
+    for im in warm:                                                                   # ~240 tables of other geometries
+        ingest.imresize(im, 32)
+    shapes = [(64 + 3 * i, 200 - i) for i in range(150)]
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3)).astype(np.uint8)).to(cuda_device) for h, w in shapes]
+    plans = [ingest._plan(im, 48) for im in imgs]
+    u8, _ = ingest.resize_many(imgs, plans)
+    torch.cuda.synchronize()
+    for im, (size, factors, box), a in zip(imgs, plans, u8):
+        assert torch.equal(a, ingest.resize(im, size[0], size[1], factors, box)[0])
+
+
 def test_hub_device_transform(cuda_device):
     """net.transform_device(decoded uint8 image) == ingest with the network's own mean / std / CLAHE settings, and feeds the net"""
     import hubconf

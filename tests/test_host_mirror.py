@@ -183,7 +183,7 @@ def test_input_wrappers_fold_into_one_transform():
 
     class Fake:
         accepts_input_transform = True
-        input_transform = None
+        meta = {"in_channels": 3, "out_channels": 1}
 
         def __init__(self, kind):
             self.kind = kind
@@ -206,6 +206,20 @@ def test_input_wrappers_fold_into_one_transform():
     # a wrapper with a postprocess of its own in last position blocks the fold
     mixed = initialize_wrappers("rgb2bgr_pre, fakebatch", "cpu")
     assert mixed._fold_input_wrappers(Fake("cuda"))[1] is None
+    # mean / std given as one broadcast value per side (mean2tensor accepts it) is not a per-channel list of the model's channel
+    # count: not folded, the wrapper runs on the host as in the reference
+    scalarish = initialize_wrappers("meanstd_pre:[[0.5],[0.5]]:[[0.4],[1]]", "cpu")
+    assert scalarish._fold_input_wrappers(Fake("cuda"))[1] is None
+    # only SingleNetwork.forward asks for the fold; a container whose hoisted wrappers act on the chain input does not
+    seen = {}
+
+    def inference(t, **kw):
+        seen.update(kw)
+        return t
+    chain(torch.rand(1, 3, 4, 4), inference, outputmodel=Fake("cuda"))
+    assert "input_transform" not in seen
+    chain(torch.rand(1, 3, 4, 4), inference, outputmodel=Fake("cuda"), fold_input=True)
+    assert seen["input_transform"][0] == (2, 1, 0)
 
 
 def test_cir_sequential_chain_config5():
@@ -280,12 +294,14 @@ def test_infer_stage_contract(tmp_path):
 
 
 def test_validate_stage_contract():
-    """validate(params, data) -> (metadata, ranks, scores): batch-1 descriptor extraction + the reference's two scoring lines
-    (mdir/stages/validate.py:15-39, cirscore.py:51-73, imageretrievalnet.py:312-339); without queries the database queries itself"""
+    """validate(params, data) -> (metadata,) as the reference's stage (mdir/stages/validate.py:15-39: a 1-tuple; dataset / criterion
+    parameters it cannot honour are rejected, not ignored); rank_images -> (metadata, ranks, scores): descriptor extraction + the
+    reference's two scoring lines (cirscore.py:51-73, imageretrievalnet.py:312-339); without queries the database queries itself"""
     from gandtr_amd.stages import FUNCTIONS
     from gandtr_amd.stages.validate import extract_vectors
     import mdir.stages.validate as aliased
     validate = FUNCTIONS["mdir.stages.validate.validate"]
+    rank_images = FUNCTIONS["gandtr_amd.stages.validate.rank_images"]
     assert aliased.validate is validate
     emb = {"type": "SingleNetwork",
            "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
@@ -297,18 +313,30 @@ def test_validate_stage_contract():
     qs = [db[3] + 0.01 * synth.synth_input(50, db[3].shape), db[0]]
     params = {"network": emb, "validation": {}, "data": {}}
     import copy
-    meta, ranks, scores = validate(copy.deepcopy(params), (db, qs))
+    out = validate(copy.deepcopy(params), (db, qs))
+    assert isinstance(out, tuple) and len(out) == 1 and set(out[0]) == {"eval", "retrieval"}          # the reference's arity
+    meta, ranks, scores = rank_images({"network": copy.deepcopy(emb)}, (db, qs))
+    assert np.array_equal(out[0]["retrieval"]["ranks"], ranks) and np.array_equal(out[0]["retrieval"]["scores"], scores)
     assert ranks.shape == (5, 2) and scores.shape == (5, 2) and meta["eval"] == {**meta["eval"], "database": 5, "queries": 2, "dim": 512}
     assert ranks[0, 0] == 3 and ranks[0, 1] == 0 and abs(scores[0, 1] - 1.0) < 1e-4       # a perturbed / identical copy ranks first
     assert all(sorted(ranks[:, j]) == list(range(5)) for j in range(2))
     assert np.all(np.diff(np.take_along_axis(scores, ranks, 0), axis=0) <= 0)              # best first
-    meta, ranks, scores = validate(copy.deepcopy(params), (db,))
+    meta, ranks, scores = rank_images({"network": copy.deepcopy(emb)}, (db,))
     assert ranks.shape == (5, 5) and list(ranks[0]) == list(range(5))                      # every image retrieves itself first
     with pytest.raises(AssertionError):
         validate({"network": emb, "data": {}}, (db,))
+    with pytest.raises(NotImplementedError):                                               # a reference scenario's validation block
+        validate({"network": copy.deepcopy(emb), "validation": {"type": "cirtorch", "dataset": "roxford5k"}, "data": {}}, (db,))
+    with pytest.raises(NotImplementedError):
+        validate({"network": copy.deepcopy(emb), "validation": {}, "data": {"test": {"dataset": "x"}}}, (db,))
     import gandtr_amd.learning as L
     net = L.load_network(copy.deepcopy(emb), "cpu")
     assert extract_vectors(net, [], "cpu").shape == (512, 0)
+    # equal-size grouping (one forward per group of same-size images) == the reference's image-by-image loop, input order kept
+    net.model.load_state_dict(synth.vgg16_state(0))
+    loop = extract_vectors(net, db, "cpu", batched=False)
+    grouped = extract_vectors(net, db, "cpu", batched=True, max_batch=2)
+    assert grouped.shape == loop.shape == (512, 5) and float((grouped - loop).abs().max()) < 1e-6
 
 
 def test_hub_networks_carry_a_device_transform():
