@@ -24,11 +24,12 @@
 #include <cstdlib>
 
 #include <type_traits>
+#include <vector>
 
 #include "gdt_common.h"
 
 // timing-only ablations (profiles/experiments): compile with -DGDT_C_ABL=<bits>; results are wrong by design
-//   1 no halo staging after the prologue   2 no MX MFMAs / MX weight loads   4 no fp16 weight re-loads   8 no fp16 MFMAs
+//   1 no halo staging after the prologue   2 no MX MFMAs / MX weight loads   4 no fp16 weight re-loads   8 no fp16 MFMAs   256 no fp16 fragment re-loads
 #ifndef GDT_C_ABL
 #define GDT_C_ABL 0
 #endif
@@ -39,6 +40,17 @@
 #endif
 #ifndef GDT_C_DEPTH_RES
 #define GDT_C_DEPTH_RES 1
+#endif
+// cache policy of the streamed loads: bit 1 = weight fragments, bit 2 = halo pieces are fetched non-temporal (the line is not kept in the
+// CU's 32 KB L1: with two substeps of weights per wave in flight the outstanding lines alone fill it)
+#ifndef GDT_C_NT
+#define GDT_C_NT 0
+#endif
+#ifndef GDT_C_SCHED
+#define GDT_C_SCHED 2          // 1: loads after each column's MFMAs (clumped)   2: one load per two MFMAs (+0.3 % images/s)
+#endif
+#ifndef GDT_C_WSTAG
+#define GDT_C_WSTAG 0           // s_sleep units (64 cycles) of start offset between consecutive waves after each chunk barrier
 #endif
 #ifndef GDT_C_CT_SKIP
 #define GDT_C_CT_SKIP 1
@@ -56,7 +68,7 @@ constexpr int Q_BYTES = HALO_ROWS_PAD * QROWB;             // 20992
 constexpr int STAGE_BYTES = A_BYTES + Q_BYTES;             // 62976
 constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
 constexpr int BM = PH * 16;
-constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES + 4 * 4096;        // + one 4 KB epilogue patch per wave
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES + 4 * 8192;        // + two 4 KB epilogue patches per wave
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -148,8 +160,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         Pend p;
         p.goff = (((unsigned)((ta.n * d.H + ry) * d.W + rx) << (d.lc8 + (S2 ? 3 : 5))) + cbyte);      // byte offset (< 2^32, checked on the host)
         p.ok = (h < HROWS) & (inb | refl);
-        p.r0 = *(const float4*)((const char*)inf + p.goff); p.r1 = *(const float4*)((const char*)inf + p.goff + 16);
-        if (RES && !(GDT_C_ABL & 32)) { p.s0 = *(const float4*)((const char*)resf + p.goff); p.s1 = *(const float4*)((const char*)resf + p.goff + 16); }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        auto ldh = [](const float4* q) -> float4 {
+            if constexpr ((GDT_C_NT & 2) != 0) { const f32x4 v = __builtin_nontemporal_load((const f32x4*)q); return make_float4(v[0], v[1], v[2], v[3]); }
+            else return *q;
+        };
+        p.r0 = ldh((const float4*)((const char*)inf + p.goff)); p.r1 = ldh((const float4*)((const char*)inf + p.goff + 16));
+        if (RES && !(GDT_C_ABL & 32)) { p.s0 = ldh((const float4*)((const char*)resf + p.goff)); p.s1 = ldh((const float4*)((const char*)resf + p.goff + 16)); }
         return p;
     };
     float* nlds = (float*)(smem + 2 * STAGE_BYTES);
@@ -238,7 +255,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // RING substep slices and substep u re-loads the slot that substep u - 1 has just finished with (slice u + RING - 1); the MX
     // fragments of group g (32 k-values, MFMAs at the end of substep 2g + 1) are re-loaded with group g + 1 early in substep 2g + 2.
     // Each substep issues its loads row by row between its MFMAs.
-    constexpr int RING = SHIFT ? 4 : 3;
+#ifndef GDT_C_RING
+#define GDT_C_RING 3
+#endif
+    constexpr int RING = SHIFT ? 4 : GDT_C_RING;
     static_assert(SLOTS % RING == 0, "ring / buffer positions of a substep must not depend on the chunk");
     static_assert(TN == 4 || TN == 2, "the weight streams are grouped per 128 output channels");
     const int wgrp_of_wave = (wn * WTN) >> 7, wblk = ((wn * WTN) >> 5) & 3;      // the wave's 128-column weight group within the tile, its first 32-column block in it
@@ -253,16 +273,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         return v;
     };
     unsigned lo16 = lane_bytes(16), lo8 = lane_bytes(8), lo4 = lane_bytes(4);        // (refreshed at the top of every chunk body)
+    auto ldw = [](const auto* p) { if constexpr ((GDT_C_NT & 1) != 0) return __builtin_nontemporal_load(p); else return *p; };
     auto load_b = [&](int rs, int j, int tile_n, long ks) {       // ks: uniform k-substep index (16 k-values each)
         const char* wb = (const char*)d.w_cfrag + ((long)(tile_n * (BN / 128) + wgrp_of_wave) * nks + ks) * 4096;
-        b[rs][j] = *(const f16x8*)(wb + lo16 + (wblk + j) * 1024);
+        b[rs][j] = ldw((const f16x8*)(wb + lo16 + (wblk + j) * 1024));
     };
     auto load_bq = [&](int j, int tile_n, long ks) {     // MX fragment j of the 32-k group starting at substep ks (even)
         const long f0 = (long)(tile_n * (BN / 128) + wgrp_of_wave) * nms + (ks >> 1);
-        const v4i qa = *(const v4i*)((const char*)d.wmx_a + f0 * 4096 + lo16 + (wblk + j) * 1024);
-        const v2i qb = *(const v2i*)((const char*)d.wmx_b + f0 * 2048 + lo8 + (wblk + j) * 512);
+        const v4i qa = ldw((const v4i*)((const char*)d.wmx_a + f0 * 4096 + lo16 + (wblk + j) * 1024));
+        const v2i qb = ldw((const v2i*)((const char*)d.wmx_b + f0 * 2048 + lo8 + (wblk + j) * 512));
         bq[j] = __builtin_shufflevector(__builtin_shufflevector(qa, qa, 0, 1, 2, 3, -1, -1), __builtin_shufflevector(qb, qb, 0, 1, -1, -1, -1, -1), 0, 1, 2, 3, 6, 7);
-        bqs[j] = *(const int*)((const char*)d.wmx_s + f0 * 1024 + lo4 + (wblk + j) * 256);
+        bqs[j] = ldw((const int*)((const char*)d.wmx_s + f0 * 1024 + lo4 + (wblk + j) * 256));
     };
 
     // A fragment addresses (see conv3x3_halo_rb.hip); fp4 plane: per-lane base per tap column (+ tap row for CT) with the swizzle key
@@ -325,8 +346,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
     for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
 
+    // The four waves run the same code and leave every barrier together, so their vector-memory instructions reach the CU's one address
+    // unit in the same cycles and queue behind each other (measured: ~50 cycles of blocked issue per load, three of four waves waiting).
+    // Wave w idles w * GDT_C_WSTAG * 64 cycles after each chunk barrier: the load clusters of the waves no longer coincide.
+    auto wave_stagger = [&]() {
+#if GDT_C_WSTAG > 0
+        for (int k = 0; k < wave; ++k) __builtin_amdgcn_s_sleep(GDT_C_WSTAG);
+#endif
+    };
     int so = 0;                   // LDS offset of the halo stage of the current chunk (0 or STAGE_BYTES)
     int slot = 0;                 // (scale, shift) slot of the current tile
+#ifdef GDT_C_STAMP                 // diagnostic build (tools/build_variant.sh stamp): per-wave s_memtime totals, written to d.stamp_out only
+    unsigned long long st_body = 0, st_cbar = 0, st_tbar = 0, st_epi = 0, st_t = __builtin_amdgcn_s_memtime(), st_n = 0;
+    const unsigned long long st_begin = st_t;
+#define GDT_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - st_t; st_t = now_; }
+#else
+#define GDT_STAMP(acc)
+#endif
     for (;;) {
         const TileAt nxt = tile_at(vb + gridDim.x);
         f32x16 acc[TM][TN];
@@ -391,7 +427,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
                         if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i) && s2_on_u(u + RING - 1)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
-                        if (kk < 3) { if (s2_ld(t)) afr[i] = a_frag(i, ty, tx, kk + 1); }
+                        if (GDT_C_ABL & 256) {}                                     // (timing only: no fp16 fragment re-loads)
+                        else if (kk < 3) { if (s2_ld(t)) afr[i] = a_frag(i, ty, tx, kk + 1); }
                         else if (t < NTAP - 1) { if (s2_ld(t + 1)) afr[i] = a_frag(i, nty, ntx, 0); }
                         if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all columns are re-loaded
                             if (!(GDT_C_ABL & 64) && s2_ld(t)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
@@ -414,7 +451,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     }
                     // in-order issue: lay the substep out as MFMA, a few VALU (the halo staging), MFMA, ... with the memory operations
                     // of a column behind its MFMAs
-#ifndef GDT_C_NOSCHED
+#if GDT_C_SCHED == 2
+                    // one vector-memory instruction at a time: the L2 -> CU path takes ~1 KB per 30 cycles; a clump of loads backs
+                    // the address unit up and the in-order wave cannot issue its next MFMA until the last of them is accepted
+#pragma unroll
+                    for (int m = 0; m < TM * TN; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                        if ((m & 1) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 global load per two MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                        if ((m & 3) == 3) { __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); }
+                    }
+                    if (cu == 1) {
+#pragma unroll
+                        for (int m = 0; m < TM * TN; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            if ((m & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                        }
+                    }
+#elif !defined(GDT_C_NOSCHED)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -440,10 +498,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            GDT_STAMP(st_body)
             if (!last) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                wave_stagger();
+                GDT_STAMP(st_cbar)
                 flip_stage(STAGE_BYTES - 2 * so);
                 so = STAGE_BYTES - so;
 #pragma unroll
@@ -467,6 +528,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        GDT_STAMP(st_tbar)
 
         // ------------------------------------------------------------ epilogue, wave-private (no workgroup barrier).  MFMA operands
         // are swapped (D = W * A^T): lane (fr, fh) holds pixel fr of row block i and, in registers 4g .. 4g+3, the output channels
@@ -478,18 +540,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         if (!(d.dbg & 4)) {
             float* __restrict__ outp = (float*)d.out;
             const float* __restrict__ resp = (const float*)d.res;
-            float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * 1024;
+            float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * 2048;
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));             // (opaque copy: keeps the epilogue's addresses out of the loop's invariant set)
             const int fr_e = lane_e & 31, fh_e = lane_e >> 5, pl = lane_e >> 3, q = lane_e & 7;
             const bool relu_now = d.relu != 0;
             const int wswz = ((fr_e >> 1) & 7) << 2;
-            // Two bodies: tiles that lie wholly inside the output with no epilogue residual (every tile of the generator) run
-            // branch-free -- no per-store bounds test, statistics always accumulated, ReLU as a max with 0 or -inf; the checked body keeps
-            // the ragged edges and the residual read.  Output offsets: one 32-bit element offset per pixel row of the lane (16 per tile).
+            // Two bodies: tiles that lie wholly inside the output with no epilogue residual (every tile of the generator) run the
+            // branch-free, software-pipelined body below; the checked body keeps the ragged edges and the residual read.
             const bool full_tile = (cur.y0 + 16 <= GH) & (cur.x0 + 16 <= GW) & (cur.tile_n * BN + wn * WTN + WTN <= d.Cout) & (resp == nullptr);
-            auto epilogue = [&](auto fast_tag) {
-                constexpr bool FAST = decltype(fast_tag)::value;
+            auto epilogue_checked = [&]() {
                 // pixel row (i, k) of this lane: y = y0 + 8 wm + 2 i + (k >> 1), x = x0 + 8 (k & 1) + pl -> one per-lane base offset plus a
                 // uniform term per (i, k)
                 const int yb = cur.y0 + wm * (WTM / 16), xb = cur.x0 + pl;
@@ -500,7 +560,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                               : (unsigned)((2 * i + (k >> 1)) * GW + 8 * (k & 1)) * (unsigned)d.Cout;
                 };
                 auto row_ok = [&](int i, int k) -> bool { return (yb + 2 * i + (k >> 1) < GH) & (xb + 8 * (k & 1) < GW); };
-                const float lo = relu_now ? 0.f : -__builtin_inff();
                 constexpr int NH = TM / 4;              // 128-row statistics records per wave
                 float st1[NH][4], st2[NH][4];
 #pragma unroll
@@ -529,12 +588,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                             float4 v = *(const float4*)(patch + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
                             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                             const unsigned o = obase + roff(i, k) + coff;
-                            if (FAST) {
-                                st1[i / 4][0] += v.x; st1[i / 4][1] += v.y; st1[i / 4][2] += v.z; st1[i / 4][3] += v.w;
-                                st2[i / 4][0] += v.x * v.x; st2[i / 4][1] += v.y * v.y; st2[i / 4][2] += v.z * v.z; st2[i / 4][3] += v.w * v.w;
-                                v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
-                                *(float4*)(outp + o) = v;
-                            } else if (row_ok(i, k) & (colq < d.Cout)) {
+                            if (row_ok(i, k) & (colq < d.Cout)) {
                                 if (d.stats) {
                                     st1[i / 4][0] += v.x; st1[i / 4][1] += v.y; st1[i / 4][2] += v.z; st1[i / 4][3] += v.w;
                                     st2[i / 4][0] += v.x * v.x; st2[i / 4][1] += v.y * v.y; st2[i / 4][2] += v.z * v.z; st2[i / 4][3] += v.w * v.w;
@@ -565,7 +619,88 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                     }
                 }
             };
-            if (full_tile) epilogue(std::true_type()); else epilogue(std::false_type());
+            // The interior body of the 3x3 and stride-2 forms, software-pipelined: two patches per wave, block n + 1 is written while block n's
+            // four row reads are in flight (one LDS latency per block instead of four), the store offset is a running per-lane value
+            // (o, o + 8 Cout, o + W Cout, o + W Cout + 8 Cout, then o += 2 W Cout: three uniform constants instead of one hoisted --
+            // and spilled -- scalar per pixel row), the statistics of the wave's 256 pixels go into ONE record (the second one is
+            // written as zeros) and the 8 pixel lanes are merged by a DPP rotate, a swizzle and one permute per value.
+            auto epilogue_pipelined = [&]() {
+                const int yb = cur.y0 + wm * (WTM / 16), xb = cur.x0 + pl;
+                // one output row pair down / 8 pixels to the right, in elements (transposed form: input pixel (y, x) owns outputs (2y + py, 2x + px))
+                const unsigned rowstep = CT ? 2u * (unsigned)d.OW * (unsigned)d.phase_cout : (unsigned)GW * (unsigned)d.Cout;
+                const unsigned c8 = CT ? 16u * (unsigned)d.phase_cout : 8u * (unsigned)d.Cout;
+                const float lo = relu_now ? 0.f : -__builtin_inff();
+                auto put = [&](int blk) {
+                    const f32x16& a = acc[blk % TM][blk / TM];
+                    float* pw = patch + (blk & 1) * 1024;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(float4*)(pw + fr_e * 32 + ((8 * g + 4 * fh_e) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                };
+                put(0);
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int colq = cur.tile_n * BN + wn * WTN + j * 32 + 4 * q;
+                    const float4 bv = d.bias ? *(const float4*)(d.bias + colq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    int ct_ph = 0, ct_co = 0;
+                    if (CT) gdt_ctc_column(colq, ct_ph, ct_co);
+                    unsigned o = CT ? (unsigned)((cur.n * d.OH + 2 * yb + (ct_ph >> 1)) * d.OW + 2 * xb + (ct_ph & 1)) * (unsigned)d.phase_cout + (unsigned)ct_co
+                                    : (unsigned)((cur.n * GH + yb) * GW + xb) * (unsigned)d.Cout + (unsigned)colq;
+                    if (!CT) {               // (CT: the wave's four blocks are the four phases of the same channels: one record over all of them)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int blk = j * TM + i;
+                        const float* pr = patch + (blk & 1) * 1024;
+                        float4 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int row = 8 * k + pl;
+                            v[k] = *(const float4*)(pr + row * 32 + ((4 * q) ^ (((row >> 1) & 7) << 2)));
+                        }
+                        if (blk + 1 < TM * TN) put(blk + 1);
+                        asm volatile("" : "+v"(o));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float4 t = v[k];
+                            t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+                            s1[0] += t.x; s1[1] += t.y; s1[2] += t.z; s1[3] += t.w;
+                            s2[0] += t.x * t.x; s2[1] += t.y * t.y; s2[2] += t.z * t.z; s2[3] += t.w * t.w;
+                            t.x = fmaxf(t.x, lo); t.y = fmaxf(t.y, lo); t.z = fmaxf(t.z, lo); t.w = fmaxf(t.w, lo);
+                            *(float4*)(outp + (o + ((k & 1) ? c8 : 0u) + ((k >> 1) ? rowstep : 0u))) = t;
+                        }
+                        o += 2u * rowstep;
+                    }
+                    if (d.stats && (!CT || j == TN - 1)) {
+                        auto merge = [](float x) -> float {            // sum over the 8 lanes lane ^ {8, 16, 32}, fixed order
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));    // row_ror:8
+                            x += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));                        // lane ^ 16
+                            x += __shfl_xor(x, 32);
+                            return x;
+                        };
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] = merge(s1[e]); s2[e] = merge(s2[e]); }
+                        if (pl == 0) {
+                            constexpr int NH = TM / 4;
+                            const int rec = cur.tile_m * (BM / 128) + wm * NH;
+                            const int cstride = CT ? d.phase_cout : d.Cout;
+                            float* dst = CT ? d.stats + ((long)rec * 2) * d.phase_cout + ct_co : d.stats + ((long)(d.stats_tile_base + rec) * 2) * d.Cout + colq;
+                            *(float4*)dst = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                            *(float4*)(dst + cstride) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+#pragma unroll
+                            for (int h = 1; h < NH; ++h) {
+                                *(float4*)(dst + (long)h * 2 * cstride) = make_float4(0.f, 0.f, 0.f, 0.f);
+                                *(float4*)(dst + (long)h * 2 * cstride + cstride) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
+                        }
+                    }
+                }
+            };
+            if (full_tile) epilogue_pipelined();
+            else epilogue_checked();
         } else {
             float sacc = 0.f;
 #pragma unroll
@@ -574,6 +709,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][15];
             if (sacc == 12345.678f) ((float*)d.out)[0] = sacc;
         }
+#ifdef GDT_C_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (diagnostic only: the epilogue's stores are charged to the epilogue)
+        GDT_STAMP(st_epi)
+        ++st_n;
+#endif
         if (!nxt.valid) break;
         cur = nxt; vb += gridDim.x; slot ^= 1;
         flip_stage(STAGE_BYTES - 2 * so);
@@ -581,6 +721,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
         for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
     }
+#ifdef GDT_C_STAMP
+    if (lane == 0 && d.stamp_out) {
+        unsigned long long* o = d.stamp_out + ((long)blockIdx.x * 4 + wave) * 8;
+        o[0] = st_body; o[1] = st_cbar; o[2] = st_tbar; o[3] = st_epi; o[4] = __builtin_amdgcn_s_memtime() - st_begin; o[5] = st_n;
+    }
+#endif
 }
 
 // timing-only ablation knob: GDT_C_DBG=4 skips the epilogue
@@ -610,7 +756,27 @@ int launch_c(const ConvLaunch& d, hipStream_t stream) {
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     const int grid = vblocks < cus ? vblocks : cus;
+#ifdef GDT_C_STAMP
+    static unsigned long long* stamp_buf = nullptr;
+    static int stamp_calls = 0;
+    ConvLaunch ds = d;
+    if (!stamp_buf) GDT_CHECK_HIP(hipMalloc((void**)&stamp_buf, (size_t)cus * 4 * 8 * sizeof(unsigned long long)));
+    GDT_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)cus * 4 * 8 * sizeof(unsigned long long), stream));
+    ds.stamp_out = stamp_buf;
+    hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, ds, vblocks);
+    if (++stamp_calls % 200 < 20 && WGM * WGN == 4) {          // a few launches per variant of a sustained run
+        GDT_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)grid * 4 * 8);
+        GDT_CHECK_HIP(hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < (size_t)grid * 4; ++w) for (int k = 0; k < 6; ++k) s[k] += (double)h[w * 8 + k];
+        const double nw = grid * 4.0, nt = s[5] / nw;
+        fprintf(stderr, "[c stamp] MODE %d FORM %d BN %d: tiles/wave %.1f; per tile: chunk bodies %.0f, chunk barriers %.0f, tile barrier %.0f, epilogue %.0f cycles; total per wave %.0f\n",
+                MODE, FORM, BN, nt, s[0] / nw / nt, s[1] / nw / nt, s[2] / nw / nt, s[3] / nw / nt, s[4] / nw);
+    }
+#else
     hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, d, vblocks);
+#endif
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }

@@ -42,3 +42,22 @@ for a, b in loops:
     waits = [t for t in tr if t.startswith("[vm(") ]
     print("   vmcnt waits:", collections.Counter(re.match(r"\[vm\((\d+)\)", t).group(1) for t in waits).most_common())
     if nchar: print("".join(tr)[:nchar])
+
+# ---- issue model: one wave per SIMD issues in order; an MFMA occupies the matrix pipe for 32 cycles and the issue port for 8, so the run of
+# other instructions up to the next MFMA is free while it fits in 24 cycles.  Costs: 4 cycles per instruction, s_nop N = 4 * (N + 1)... (rough)
+def exposed(a, b):
+    run = 0; tot = 0; n_runs = 0; worst = []
+    for l in lines[a:b]:
+        s = l.strip()
+        if not s or s[0] in ";." or s.endswith(":"): continue
+        op = s.split()[0]
+        if op.startswith("v_mfma"):
+            if run > 24: tot += run - 24; worst.append(run)
+            run = 0; n_runs += 1
+        elif op.startswith("s_waitcnt") or op.startswith("s_barrier"): pass
+        elif op.startswith("s_nop"): run += 4 * (int(s.split()[1]) + 1)
+        else: run += 4
+    return tot, n_runs, sorted(worst)[-10:]
+for a, b in loops:
+    t, n, w = exposed(a, b)
+    print("loop %d..%d: %d MFMAs (%d pipe cycles), issue cycles not covered by an MFMA shadow ~%d; longest runs %s" % (a, b, n, 32 * n, t, w))
