@@ -35,8 +35,9 @@ constexpr int LOAD_ROWS8 = (HPIX + 7) / 8;       // 67 wave-wide 1 KB loads per 
 constexpr int LROWS = 552;                       // LDS rows of the halo buffer: >= NBLK * 32 - 1 + 6 * HWD + 1 = 548
 constexpr int HBYTES = LROWS * 128;              // 70,656 B: two workgroups per CU
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ROUNDS = (HPIX + NT / 8 - 1) / (NT / 8);      // 17 staging rounds of 32 halo pixels (F32IN form)
 constexpr int PSTRIDE = 33;                      // floats per partial-sum pixel (odd: the 7-tap combine is conflict free)
-static_assert(NBLK * 32 >= MROWS && NBLK * 32 * PSTRIDE * 4 <= HBYTES && LROWS >= LOAD_ROWS8 * 8 && NBLK <= 3 * NWAVE, "layout");
+static_assert(NBLK * 32 >= MROWS && NBLK * 32 * PSTRIDE * 4 <= HBYTES && LROWS >= LOAD_ROWS8 * 8 && NBLK <= 3 * NWAVE && ROUNDS * (NT / 8) <= LROWS, "layout");
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
@@ -49,10 +50,14 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // F32IN ("f16c" precision mode): the input is the fp32 NHWC tensor of that mode; the halo goes through registers (load, folded
-// InstanceNorm + ReLU in fp32, ONE rounding to fp16) instead of LDS-DMA + in-place normalisation.  The product itself stays a single
-// fp16 MFMA pass: the head is the last layer, its rounding error (3.4e-4 of the output range) is not amplified by
-// anything downstream, and the mode's budget of 1e-3 holds with it (measured 4.9e-4 pre-tanh at batch 64).
-template <bool F32IN>
+// InstanceNorm + ReLU in fp32, split into fp16(a) and the residual) instead of LDS-DMA + in-place normalisation.  With the
+// block-scaled correction operands present (d.wmx_a: packed by net.hip for the f16c head) the product is compensated like the other
+// layers of the mode (conv3x3_halo_c.hip):  a w ~= a_hi w_hi (fp16 MFMA) + [a_lo | a_hi]_fp4 . [w_hi | w_lo]_fp6 (one MX MFMA per 32
+// k-values).  LDS holds one plane at a time -- two workgroups per CU must keep fitting -- so the fp4 words (two dwords per piece, 34
+// registers per thread) wait in registers while the fp16 plane is consumed, are then written over it, and a second, shorter MFMA
+// pass (14 instead of 28 per block, weights streamed from L2) adds the correction.  A single fp16 pass left the head with 3.4e-4 of
+// the output range -- as much as the 22 compensated layers before it together (4.7e-4 pre-tanh overall; 3.1e-4 with this).
+template <bool F32IN, bool MX = false>
 __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
     const int fr = lane & 31, fh = lane >> 5;
     const int tiles_x = (d.W + PW - 1) / PW, tiles_y = (d.H + PH - 1) / PH, tpi = tiles_x * tiles_y;
     const int cout = d.Cout;
+    static_assert(F32IN || !MX, "the compensated product reads the fp32 tensor");
 
     // XCD-chunked persistent schedule: workgroup b (XCD b & 7, slot b >> 3) walks the tiles slot, slot + S, ... of its XCD's
     // contiguous span, so the CUs of one XCD hold neighbouring tiles (shared halo rows hit its L2) at any time
@@ -75,19 +81,35 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
     const int nb = wrot < NBLK - 2 * NWAVE ? 3 : 2;         // blocks wrot, wrot + 4 (, wrot + 8)
 
     // the whole B operand lives in registers: fragment ks holds k = ks * 16 + fh * 8 .. +8 of output column fr
-    f16x8 bw[4 * KT];
+    // (F32IN: the registers are needed for the fp4 words that wait for the second pass; the 28 KB matrix is then streamed L2 -> registers
+    // WRING fragments ahead, once per tile -- every wave of the chip reads the same 28 KB)
+    constexpr int NBW = F32IN ? 1 : 4 * KT, WRING = 6;
+    f16x8 bw[NBW];
+    if (!F32IN) {
 #pragma unroll
-    for (int ks = 0; ks < 4 * KT; ++ks) bw[ks] = *(const f16x8*)(d.w_frag + ((long)ks * 64 + lane) * 8);
+        for (int ks = 0; ks < 4 * KT; ++ks) bw[ks % NBW] = *(const f16x8*)(d.w_frag + ((long)ks * 64 + lane) * 8);
+    }
+    f16x8 wring[F32IN ? WRING : 1];
+    // (uniform base + 32-bit lane offset, refreshed per tile behind an opaque copy: as 64-bit per-lane addresses the 28 + 42 fragment
+    // addresses are loop invariants, which the compiler hoists out of the tile loop and spills)
+    unsigned lo16 = 0, lo8 = 0, lo4 = 0;
+    auto lane_offsets = [&]() { int l = lane; asm volatile("" : "+v"(l)); lo16 = l * 16; lo8 = l * 8; lo4 = l * 4; };
+    auto load_w = [&](int ks) { wring[ks % WRING] = *(const f16x8*)((const char*)d.w_frag + ks * 1024 + lo16); };
 
     const bool refl = d.pad_reflect != 0;
     // A fragment of partial-sum pixel m = block * 32 + fr for kernel row ky: halo pixel m + ky * 38.  The swizzle term
     // depends on the row modulo 16 only, and a block shifts the row by a multiple of 32: one address set serves every block.
+    // (MX: recomputed per tile from an opaque copy of the lane id -- with the fp4 words parked in registers the kernel sits at its 256-register
+    // budget, and every per-lane loop invariant the compiler hoists out of the persistent tile loop is one more spilled register)
     int a_base[KT];
+    auto set_a_base = [&](int fr_, int fh_) {
 #pragma unroll
-    for (int ky = 0; ky < KT; ++ky) {
-        const int row = wrot * 32 + fr + ky * HWD;
-        a_base[ky] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
-    }
+        for (int ky = 0; ky < KT; ++ky) {
+            const int row = wrot * 32 + fr_ + ky * HWD;
+            a_base[ky] = row * 128 + ((fh_ ^ ((row >> 1) & 7)) << 4);
+        }
+    };
+    if (!MX) set_a_base(fr, fh);
     // (scale, shift) of the folded InstanceNorm for 16-byte channel group tid & 7 of the current image
     const int c8 = tid & 7;
 
@@ -99,6 +121,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
 #pragma unroll
             for (int k = 0; k < 4; ++k) nv[k] = *(const float4*)(d.in_norm + ((long)n * 64 + c8 * 8) * 2 + k * 4);
         }
+        unsigned qq[MX ? ROUNDS : 1][2];              // (MX) fp4 words of the residual / the rounded value of the thread's pieces, 8 channels each
         if (F32IN) {
             // ---- halo through registers: thread t handles 8-channel group t & 7 of pixels (t >> 3) + 32 j
             const float* __restrict__ inf = (const float*)d.in;
@@ -111,11 +134,13 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             const float lo = (d.in_norm && d.in_relu) ? 0.f : -3.0e38f;
             int t8 = tid >> 3;
             asm volatile("" : "+v"(t8));
+            const int wbase = t8 * 128 + ((c8 ^ ((t8 >> 1) & 7)) << 4);
             // rolling pipeline: round j's two 16-byte loads are issued RING rounds before they are converted and written to LDS, so the
             // memory latency is paid once per tile (in batches of four rounds it was paid five times: 17 us per tile, 0.55 ms per launch)
-            constexpr int ROUNDS = (HPIX + NT / 8 - 1) / (NT / 8), RING = 4;
+            constexpr int RING = 4;
             float4 ring[RING][2];
             unsigned okmask = 0;
+            const float lo_scale = __builtin_ldexpf(1.f, -d.c_lo_exp), hi_scale = __builtin_ldexpf(1.f, d.c_hi_exp);   // the converts divide by their scale
             auto issue = [&](int j, float4 (&rg)[2]) {
                 const int hp = t8 + j * (NT / 8);
                 const int hy = (hp * 1725) >> 16, hx = hp - hy * HWD;
@@ -129,18 +154,32 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                 rg[0] = *(const float4*)src; rg[1] = *(const float4*)(src + 4);
             };
             auto finish = [&](int j, const float4 (&rg)[2]) {
-                const int hp = t8 + j * (NT / 8);
                 const bool ok = (okmask >> j) & 1u;
                 const float a[8] = {rg[0].x, rg[0].y, rg[0].z, rg[0].w, rg[1].x, rg[1].y, rg[1].z, rg[1].w};
                 u32x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float p0 = fmaxf(fmaf(a[2 * k], sc[2 * k], sh[2 * k]), lo), p1 = fmaxf(fmaf(a[2 * k + 1], sc[2 * k + 1], sh[2 * k + 1]), lo);
-                    unsigned w;
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(p0), "v"(p1));
-                    o[k] = ok ? w : 0u;
+                unsigned qlo = 0, qhi = 0;
+                // per channel pair k: normalise, round to fp16 (two per instruction); (MX) residuals p - fp16(p) in one v_fma_mix each, both
+                // planes to fp4 by the scaled converts (the byte select must be a literal: hence the macro; see conv3x3_halo_c.hip)
+#define GDT_H7_PAIR(k)                                                                                                                     \
+                {                                                                                                                          \
+                    const float p0 = fmaxf(fmaf(a[2 * k], sc[2 * k], sh[2 * k]), lo), p1 = fmaxf(fmaf(a[2 * k + 1], sc[2 * k + 1], sh[2 * k + 1]), lo); \
+                    unsigned w;                                                                                                            \
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(p0), "v"(p1));                                                       \
+                    if (MX) {                                                                                                              \
+                        float l0, l1;                                                                                                      \
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(w), "v"(p0));                \
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(w), "v"(p1));                \
+                        qlo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qlo, l0, l1, lo_scale, k);                                          \
+                        qhi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(qhi, __builtin_bit_cast(f16x2, w), hi_scale, k);                     \
+                    }                                                                                                                      \
+                    o[k] = ok ? w : 0u;                                                                                                    \
                 }
-                if (hp < LROWS) *(u32x4*)(smem + hp * 128 + ((c8 ^ ((hp >> 1) & 7)) << 4)) = o;
+                GDT_H7_PAIR(0) GDT_H7_PAIR(1) GDT_H7_PAIR(2) GDT_H7_PAIR(3)
+#undef GDT_H7_PAIR
+                if (MX) { qq[MX ? j : 0][0] = ok ? qlo : 0u; qq[MX ? j : 0][1] = ok ? qhi : 0u; }
+                // row hp = t8 + 32 j: the swizzle term (hp >> 1) & 7 does not depend on j, so the 17 addresses are one base + j * 4 KB
+                // (ROUNDS * 32 <= LROWS: every row exists)
+                *(u32x4*)(smem + wbase + j * (NT / 8) * 128) = o;
             };
 #pragma unroll
             for (int j = 0; j < RING; ++j) issue(j, ring[j]);
@@ -148,6 +187,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             for (int j = 0; j < ROUNDS; ++j) {
                 finish(j, ring[j % RING]);
                 if (j + RING < ROUNDS) issue(j + RING, ring[j % RING]);
+                if (MX) __builtin_amdgcn_sched_barrier(0);        // (round by round: interleaved across rounds the 17 unrolled rounds spill)
             }
             lds_barrier();
         } else {
@@ -207,6 +247,10 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
         }
 
         // ---- GEMM over the kernel rows: 2 or 3 independent accumulator chains per wave
+        int lane_t = lane;
+        if (MX) { asm volatile("" : "+v"(lane_t)); set_a_base(lane_t & 31, lane_t >> 5); }
+        const int fr_t = lane_t & 31, fh_t = lane_t >> 5;
+        const int b2 = nb == 3 ? 2 : 1;
         f32x16 acc[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -214,30 +258,83 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
         if (!(d.dbg & 2)) {
             constexpr int PF = 3;                                  // fragment sets in flight (LDS latency vs 3 MFMAs per set)
+            // (MX form: every wave issues three MFMA chains -- the waves that own two blocks repeat their second one and drop the result: with
+            // the branches of the two-or-three form around 28 + 14 unrolled steps the register allocator spilled ~230 registers)
             f16x8 afr[PF][3];
             auto frags = [&](int ks, f16x8 (&f)[3]) {
                 const int off = a_base[ks >> 2] ^ ((ks & 3) << 5);
                 f[0] = *(const f16x8*)(smem + off);
                 f[1] = *(const f16x8*)(smem + off + NWAVE * 32 * 128);
-                if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
+                if (MX) f[2] = *(const f16x8*)(smem + off + b2 * (NWAVE * 32 * 128));          // (b2 = 1 for the waves with two blocks: a duplicate, discarded)
+                else if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
             };
 #pragma unroll
             for (int p = 0; p < PF - 1; ++p) frags(p, afr[p]);
+            if (F32IN) {
+                lane_offsets();
+#pragma unroll
+                for (int p = 0; p < WRING - 1; ++p) load_w(p);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4 * KT; ++ks) {
                 if (ks + PF - 1 < 4 * KT) frags(ks + PF - 1, afr[(ks + PF - 1) % PF]);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], bw[ks], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], bw[ks], acc[1], 0, 0, 0);
-                if (nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], bw[ks], acc[2], 0, 0, 0);
+                if (F32IN && ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
+                const f16x8 wk = F32IN ? wring[ks % WRING] : bw[ks % NBW];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], wk, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], wk, acc[1], 0, 0, 0);
+                if (MX || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);
             }
         }
         lds_barrier();                                 // the halo has been consumed by every wave
+        if constexpr (MX) {
+            // ---- correction pass: the fp4 plane over the consumed halo -- 64-byte rows [lo 0-31 | hi 0-31 | lo 32-63 | hi 32-63], 16-byte
+            // pieces XOR-swizzled by (row >> 2) & 3 (conflict-free 16-lane fragment reads) -- then 14 MX MFMAs per block, weight fragments
+            // (conv3x3_halo_c.hip layout: 16 + 8 bytes of e2m3 values and one E8M0 scale dword per lane) streamed L2 -> registers one ahead
+            int t8 = tid >> 3;
+            asm volatile("" : "+v"(t8));
+            // row hp = t8 + 32 j, piece (2 * (c8 >> 2) + {lo 0, hi 1}) ^ ((hp >> 2) & 3): again independent of j -> one base + j * 2 KB
+            const int qbase = t8 * 64 + ((((c8 >> 2) << 1) ^ ((t8 >> 2) & 3)) << 4) + ((c8 & 3) << 2);
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) {
+                *(unsigned*)(smem + qbase + j * (NT / 8) * 64) = qq[j][0];
+                *(unsigned*)(smem + (qbase ^ 16) + j * (NT / 8) * 64) = qq[j][1];
+            }
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            typedef int v6i __attribute__((ext_vector_type(6)));
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            v6i wq[2]; int wqs[2];
+            auto load_wq = [&](int slot, int ms) {
+                const v4i qa = *(const v4i*)((const char*)d.wmx_a + ms * 4096 + lo16);
+                const v2i qb = *(const v2i*)((const char*)d.wmx_b + ms * 2048 + lo8);
+                wq[slot] = __builtin_shufflevector(__builtin_shufflevector(qa, qa, 0, 1, 2, 3, -1, -1), __builtin_shufflevector(qb, qb, 0, 1, -1, -1, -1, -1), 0, 1, 2, 3, 6, 7);
+                wqs[slot] = *(const int*)((const char*)d.wmx_s + ms * 1024 + lo4);
+            };
+            load_wq(0, 0);
+            lds_barrier();
+            const int a_scale = fh_t ? 127 + d.c_hi_exp : 127 - d.c_lo_exp;       // lanes 0-31 carry a_lo * 2^c_lo_exp, lanes 32-63 a_hi * 2^-c_hi_exp
+            const int qrow0 = wrot * 32 + fr_t;
+#pragma unroll
+            for (int ms = 0; ms < 2 * KT; ++ms) {
+                if (ms + 1 < 2 * KT) load_wq((ms + 1) & 1, ms + 1);
+                const int row = qrow0 + (ms >> 1) * HWD;
+                const int off = row * 64 + (((((ms & 1) << 1) | fh_t) ^ ((row >> 2) & 3)) << 4);
+                const v8i wv = __builtin_shufflevector(wq[ms & 1], wq[ms & 1], 0, 1, 2, 3, 4, 5, -1, -1);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                        const v4i av4 = *(const v4i*)(smem + off + (b == 2 ? b2 : b) * (NWAVE * 32 * 64));
+                        const v8i av = __builtin_shufflevector(av4, av4, 0, 1, 2, 3, -1, -1, -1, -1);
+                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, wv, acc[b], 4, 2, 0, a_scale, 0, wqs[ms & 1]);
+                    }
+            }
+            lds_barrier();                             // the fp4 plane has been consumed
+        }
         float* P = (float*)smem;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
             if (b < nb) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) P[((wrot + b * NWAVE) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * PSTRIDE + fr] = acc[b][e];
+                for (int e = 0; e < 16; ++e) P[((wrot + b * NWAVE) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh_t) * PSTRIDE + fr_t] = acc[b][e];
             }
         lds_barrier();
         for (int idx = tid; idx < cout * PH * PW && !(d.dbg & 4); idx += NT) {
@@ -274,6 +371,7 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
         cus = cus / 8 * 8;
         GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
     static const int wgs = [] { const char* e = getenv("GDT_HEAD7_WGS"); return e ? atoi(e) : 2; }();
@@ -281,7 +379,8 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_HEAD7_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch dd = d;
     dd.dbg = dbg;
-    if (d.in_f32) hipLaunchKernelGGL(conv_head7_kernel<true>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    if (d.in_f32 && d.wmx_a && d.wmx_b && d.wmx_s) hipLaunchKernelGGL((conv_head7_kernel<true, true>), dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    else if (d.in_f32) hipLaunchKernelGGL(conv_head7_kernel<true>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     else hipLaunchKernelGGL(conv_head7_kernel<false>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;

@@ -120,6 +120,7 @@ struct gdt_net {
     bool finalized = false;
     int input_op = -1;
     int precision = 0;                      // 0: fp16 activations, single MFMA pass; 1: "f16x3" (fp32 activations, split operands);
+    bool head_comp = false;                 // precision mode 3: f16c with the generator head compensated too (conv_head7.hip MX pass)
                                             // 2: "f16c" (fp32 activations, fp16 product + block-scaled fp4 x fp6 correction product where a
                                             //    compensated kernel exists, f16x3 kernels elsewhere)
     size_t esize() const { return precision ? sizeof(float) : sizeof(f16); }
@@ -539,8 +540,9 @@ int quant_e2m3(float x) {
 void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<unsigned char>& a, std::vector<unsigned char>& b,
              std::vector<unsigned>& sc, std::vector<f16>& wc) {
     const int ncb = cout_pad / 32, nms = Kpad / 32, nks = Kpad / 16;
-    a.assign((size_t)ncb * nms * 64 * 16, 0); b.assign((size_t)ncb * nms * 64 * 8, 0); sc.assign((size_t)ncb * nms * 64, 0);
-    wc.assign((size_t)cout_pad * Kpad, (f16)0.f);
+    const size_t ncb4 = (size_t)(ncb + 3) / 4 * 4;            // whole groups of four 32-channel blocks (the head has a single block)
+    a.assign(ncb4 * nms * 64 * 16, 0); b.assign(ncb4 * nms * 64 * 8, 0); sc.assign(ncb4 * nms * 64, 0);
+    wc.assign(ncb4 * 32 * (size_t)Kpad, (f16)0.f);
     for (int cb = 0; cb < ncb; ++cb)
         for (int ks = 0; ks < nks; ++ks)
             for (int ln = 0; ln < 64; ++ln) {
@@ -607,8 +609,9 @@ int gdt_net_create(gdt_net** net) {
 
 int gdt_net_set_precision(gdt_net* net, int mode) {
     GDT_REQUIRE(net && !net->finalized && net->ops.empty(), "precision must be chosen before the first op");
-    GDT_REQUIRE(mode == 0 || mode == 1 || mode == 2, "precision mode: 0 = f16, 1 = f16x3, 2 = f16c");
-    net->precision = mode;
+    GDT_REQUIRE(mode >= 0 && mode <= 3, "precision mode: 0 = f16, 1 = f16x3, 2 = f16c, 3 = f16ch (f16c + compensated head)");
+    net->precision = mode == 3 ? 2 : mode;
+    net->head_comp = mode == 3;
     return GDT_OK;
 }
 
@@ -788,6 +791,21 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     }
                 ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
                 ph.has_frag = true;
+                if (net->precision == 2 && net->head_comp) {       // "f16ch": block-scaled correction operands of the same [32][Kpad] matrix (conv_head7.hip, second pass)
+                    std::vector<float> wf((size_t)o.cout_pad * ph.Kpad, 0.f);
+                    for (int kx = 0; kx < cd.kw; ++kx)
+                        for (int co = 0; co < cd.cout; ++co)
+                            for (int ky = 0; ky < cd.kh; ++ky)
+                                for (int c = 0; c < cd.cin; ++c)
+                                    wf[(size_t)(kx * cd.cout + co) * ph.Kpad + (size_t)ky * cin_pad + c] = weight[(((size_t)co * cd.cin + c) * cd.kh + ky) * cd.kw + kx];
+                    std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
+                    pack_mx(wf, o.cout_pad, ph.Kpad, ma, mb, msc, wc);
+                    ph.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
+                    ph.wmx_a_off = net->blob_append(ma.data(), ma.size());
+                    ph.wmx_b_off = net->blob_append(mb.data(), mb.size());
+                    ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
+                    ph.has_mx = true;
+                }
             }
         }
         o.phases.push_back(ph);

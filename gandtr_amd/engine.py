@@ -37,7 +37,7 @@ def _ptr(a):
 class HipNet:
     """One layer graph living on one GPU.  Not re-entrant (same rule as the C handle)."""
 
-    PRECISIONS = {"f16": 0, "f16x3": 1, "f16c": 2}
+    PRECISIONS = {"f16": 0, "f16x3": 1, "f16c": 2, "f16ch": 3}       # include/gandtr_hip.h, gdt_net_set_precision
 
     def __init__(self, device, precision="f16"):
         self.lib = _hip.load()

@@ -51,7 +51,12 @@ void gdt_net_destroy(gdt_net* net);
  *   0 "f16"   (default): fp16 NHWC activations, one fp16 MFMA pass, fp32 accumulation (11-bit operands).
  *   1 "f16x3": fp32 NHWC activations; every operand is split into two fp16 numbers and three MFMA passes are accumulated
  *              (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): fp32-class accuracy at 3x the matrix work.  Used where the reference's
- *              fp32 result has to be matched to 1e-3 through deep random-weight stacks. */
+ *              fp32 result has to be matched to 1e-3 through deep random-weight stacks.
+ *   2 "f16c":  fp32 NHWC activations; fp16 MFMA product + one block-scaled fp4 x fp6 MFMA per 32 k-values that carries both rounding
+ *              residuals (1.5x the matrix work): 1e-3-class accuracy; the generators' default.  The last layer (7x7 head) runs a single
+ *              fp16 pass on the fp32 tensor.
+ *   3 "f16ch": f16c with the head compensated as well (second MFMA pass over an fp4 plane): pre-tanh error 4.7e-4 -> 3.1e-4 of the
+ *              range for +0.5 ms per 64 x 256^2 batch. */
 int gdt_net_set_precision(gdt_net* net, int mode);
 
 /* External fp32 NCHW image input with C <= 8 channels (packed to fp16 NHWC8 on entry).  Optional channel permutation

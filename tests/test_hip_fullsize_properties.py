@@ -82,6 +82,48 @@ def test_embedder_1024_properties(cuda_device, arch, n):
     assert torch.allclose(w, v / (v.norm(dim=1, keepdim=True) + 1e-6), atol=1e-6)
 
 
+@pytest.mark.parametrize("arch", ["resnet101", "vgg16"])
+def test_embedder_bench_geometry_against_oracle(cuda_device, arch):
+    """The geometries bench.py / bench_configs.py quote numbers on -- GeM-ResNet-101 and GeM-VGG16 at 32 x 3 x 1024 x 1024 (BASELINE
+    configs 2 and the secondary headline) -- against the CPU oracle on two of the 32 images.  Kernel choice depends on the tile count
+    (conv3x3_halo_rb / conv1x1_rb thresholds), so batch 32 runs variants that batch 4 / 8 do not: north_star's gates hold HERE:
+    cosine >= 0.9999, ||d||inf <= 1e-3."""
+    from oracle import gandtr_oracle as O
+    sd = synth.resnet101_state(0) if arch == "resnet101" else synth.vgg16_state(0)
+    net = engine.build_embedder(sd, cuda_device)
+    x = synth.synth_input(43, (32, 3, 1024, 1024))
+    d = net.forward(x.to(cuda_device))[net.out_slot].cpu()                                    # N x D
+    assert d.shape == (32, 2048 if arch == "resnet101" else 512)
+    for i in (3, 31):
+        ref = O.image_retrieval_forward(x[i:i + 1], sd, arch).t().contiguous()[0]
+        cos = float(torch.nn.functional.cosine_similarity(d[i], ref, dim=0))
+        err = float((d[i] - ref).abs().max())
+        print("%s batch 32 @1024, image %d: cos %.7f, |d|inf %.2e" % (arch, i, cos, err))
+        assert cos >= 0.9999 and err <= 1e-3, (i, cos, err)
+
+
+def test_resnet101_sms_pyramid_at_1024_against_oracle(cuda_device):
+    """BASELINE config 4's `sms` preset {1, 1/sqrt2, sqrt2} on a 1 x 3 x 1024 x 1024 image: the 1448 x 1448 level (bilinear
+    up-sampling inside the input-pack kernel, the largest tensors of any config) + aggregation + learned whitening against
+    O.embed_ms_whiten (mdir/components/data/wrapper.py:197-263, 308-322): cosine >= 0.9999, ||d||inf <= 1e-3."""
+    from oracle import gandtr_oracle as O
+    sd = synth.resnet101_state(0, p=3.0)
+    lw = synth.whitening_state(0, 2048)
+    P, m = torch.from_numpy(lw["P"]), torch.from_numpy(lw["m"])
+    x = synth.synth_input(44, (1, 3, 1024, 1024))
+    scales = O.SCALE_PRESETS["sms"]
+    ref = O.embed_ms_whiten(x, sd, "resnet101", scales, P, m).reshape(-1)
+    net = engine.build_embedder(sd, cuda_device)
+    xd = x.to(cuda_device)
+    per_scale = torch.stack([net.forward(xd, scale=s)[net.out_slot] for s in scales])       # S x 1 x D
+    v = engine.ms_aggregate(per_scale, 3.0)
+    got = engine.whiten(v, P.to(cuda_device), m.to(cuda_device)).cpu().reshape(-1)
+    cos = float(torch.nn.functional.cosine_similarity(got, ref, dim=0))
+    err = float((got - ref).abs().max())
+    print("resnet101 sms @1024 (1448 level): cos %.7f, |d|inf %.2e" % (cos, err))
+    assert cos >= 0.9999 and err <= 1e-3, (cos, err)
+
+
 def test_descriptor_op_identities(cuda_device):
     v = torch.rand(3, 5, 256, device=cuda_device) + 0.1
     same = v[:1].expand(3, 5, 256).contiguous()

@@ -48,12 +48,17 @@ def test_hub_generator_on_gpu(cuda_device, name):
         y = net(x)
     assert y.is_cuda and y.shape == (4, 3, 256, 256)
     y = y.cpu()
-    # the reference's own output on the same seed-0 weights (tests/golden/make_golden.py).  gain-0.2 init drives |pre-tanh| to ~30
-    # (SURVEY.md D6): north_star's 1e-3 of the pre-tanh range is 3e-2 in front of the tanh, so outputs near a zero crossing may move by
-    # that much while the image as a whole agrees to 5e-4 in the mean (measured 2.5e-4; the single-pass fp16 mode: 1.8e-3, the gate
-    # this test had in round 1: 5e-3).  The tight per-tap comparison lives in test_hip_models.py.
-    diff = (y[:, :, ::8, ::8] - torch.from_numpy(g["out_sub"])).abs()
-    assert float(diff.mean()) < (5e-4 if name == "cyclegan" else 1e-3), float(diff.mean())
+    # the reference's own output on the same seed-0 weights (tests/golden/make_golden.py).  These fixtures are SATURATED: cyclegan's gain-0.2
+    # init drives |pre-tanh| to ~35, hedngan's kaiming / BatchNorm init to several hundred, so north_star's 1e-3 of the pre-tanh
+    # range is 3.5e-2 / ~0.3 in front of the tanh and outputs near a zero crossing move by that much while the image as a whole agrees to
+    # < 5e-4 in the mean.  All three statistics are gated, each with its measured value next to it (tools/parity_report.py, round 3):
+    #   cyclegan  mean 2.97e-4   p99.9 7.5e-3   max 9.6e-3        hedngan  mean 4.93e-4   p99.9 0.100   max 0.259
+    # (single-pass fp16 mode: mean 1.8e-3; the unsaturated absolute gate, max|d image| <= 1e-3, is test_hip_models.py::test_generator_image_absolute_gate)
+    diff = (y[:, :, ::8, ::8] - torch.from_numpy(g["out_sub"])).abs().flatten()
+    mean, p999, mx = float(diff.mean()), float(torch.quantile(diff, 0.999)), float(diff.max())
+    print("hub %s vs the reference's output: mean %.2e, p99.9 %.2e, max %.2e" % (name, mean, p999, mx))
+    gate = {"cyclegan": (5e-4, 1.5e-2, 3.5e-2), "hedngan": (1e-3, 0.2, 0.5)}[name]
+    assert mean < gate[0] and p999 < gate[1] and mx < gate[2], (mean, p999, mx)
 
 
 @pytest.mark.parametrize("arch,p", [("vgg16", 3.0), ("resnet101", 2.37)])
@@ -157,4 +162,5 @@ def test_hub_generator_precision_switch(cuda_device, monkeypatch):
         net.model.hip_precision = "f16x3"
         exact = net(x).cpu()[:, :, ::8, ::8]
     e_default, e_fast, e_exact = (float((t - ref).abs().mean()) for t in (default, fast, exact))
-    assert e_exact < 2e-5 and e_default < 5e-4 and e_default < e_fast / 5, (e_default, e_fast, e_exact)
+    # measured (round 3): f16c 2.97e-4, f16 1.8e-3, f16x3 1e-5 -- mean |d image| on the saturated seed-0 fixture (see test_hub_generator_on_gpu)
+    assert e_exact < 2e-5 and e_default < 3.5e-4 and e_default < e_fast / 5, (e_default, e_fast, e_exact)
