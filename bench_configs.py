@@ -8,6 +8,14 @@
   c4  augment-then-embed: cyclegan on 128x3x256x256 -> meanstd_post -> GeM-ResNet101  -> images/s
       (+ the same chain with the reference's clahepost step, and the CLAHE / retrieval 'next' rows alone)
 Everything runs through the hub / wrapper / network-container API of the host mirror (the drop-in surface).
+
+`python bench_configs.py --gpus N` runs BASELINE configs 4 and 5 as north_star states them -- one process per GPU (the script starts its own
+`torch.distributed.run` child, as bench.py does), weights replicated, the batch sharded in contiguous chunks, ONE RCCL all-gather of the
+descriptor block at the end (generator outputs are not gathered):
+  c3  per-rank chunk (8 x 3x1024x1024) -> 3-scale pyramid -> GeM-ResNet101 -> multi-scale aggregation -> lw whitening -> all-gather  -> descriptors/s
+  c4  per-rank chunk (128 x 3x256x256) -> cyclegan -> meanstd_post -> GeM-ResNet101 -> all-gather                                     -> images/s
+`--dry-run` rehearses both on the CPU with gloo (tiny images, the same code path through wrappers / containers / sharding) and checks on
+every rank that the gathered D x N matrix equals, bit for bit, the single-process result over the same chunks (tests/test_bench_launcher.py).
 """
 import json
 import math
@@ -37,6 +45,126 @@ def rate(fn, units, steps=8, warmup=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return round(units / dt, 1), round(dt * 1e3, 2)
+
+
+def _c3_network(dev, scales, tmp):
+    """gem_resnet101 as the hub's pretrained call path builds it: checkpoint + lw.pkl -> whitening + multi-scale wrappers"""
+    base = hubconf.gem_resnet101_hedngan(pretrained=False, device="cpu")
+    base.model.load_state_dict(synth.resnet101_state(0))
+    sd = base.state_dict()["net"]
+    sd["network_params"]["runtime"]["data"] = {"transforms": "pil2np | totensor | normalize",
+                                               "mean_std": [[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]]}
+    ck, lw = os.path.join(tmp, "r101.pth"), os.path.join(tmp, "lw.pkl")
+    torch.save(sd, ck)
+    with open(lw, "wb") as f:
+        pickle.dump(synth.whitening_state(0, 2048), f)
+    runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": lw, "dimensions": None}, "1_cirmultiscale": {"scales": scales}}}}
+    return N.initialize_network(None, dev, Checkpoints.load_network(ck), runtime).eval()
+
+
+def _c4_chain(dev):
+    gen_p = {"type": "SingleNetwork",
+             "model": {"architecture": "official_resnet_generator", "input_nc": 3, "output_nc": 3, "n_blocks": 9,
+                       "norm_layer": "instance", "no_antialias": True, "no_antialias_up": True},
+             "initialize": False,
+             "runtime": {"wrappers": "meanstd_post:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:[[0.485,0.456,0.406],[0.229,0.224,0.225]]",
+                         "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    emb_p = {"type": "SingleNetwork",
+             "model": {"architecture": "cirnet", "cir_architecture": "resnet101", "local_whitening": False, "pooling": "gem",
+                       "pretrained": False, "regional": False, "whitening": False},
+             "initialize": False,
+             "runtime": {"wrappers": "cirfaketuplebatch",
+                         "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}}}
+    chain = N.initialize_network({"type": "CirSequentialNetwork", "sequence": "augment,embed", "augment": gen_p, "embed": emb_p}, dev).eval()
+    chain.networks["augment"].model.load_state_dict(synth.generator_state(0, "instance"))
+    chain.networks["embed"].model.load_state_dict(synth.resnet101_state(0))
+    return chain
+
+
+def sharded_main(args):
+    """configs 4 / 5 over the ranks of one node (module docstring).  Launched by `torch.distributed.run`: RANK / LOCAL_RANK / WORLD_SIZE."""
+    import torch.distributed as dist
+    from gandtr_amd import sharding
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run
+    dist.init_process_group("gloo" if dry else "nccl")
+    if dry:
+        dev = torch.device("cpu")
+        torch.set_num_threads(2)
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+        dist.barrier()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if not dry else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps
+
+    out = {"n_gpus": world, "backend": dist.get_backend(), "dry_run": dry}
+    tmp = tempfile.mkdtemp()
+    steps, warmup = (1, 0) if dry else (args.steps, 1)
+    with torch.no_grad():
+        # ---- c3: multi-scale + whitening, batch-sharded, one all-gather
+        per_rank, side = (2, 64) if dry else (8, 1024)
+        x = synth.synth_input(4, (per_rank * world, 3, side, side)).to(dev)          # every rank synthesises the same global batch
+        for tag, scales in (("hub_default", True), ("sms", "sms")):
+            net = _c3_network(dev, scales, tmp)
+            dt = timed(lambda: sharding.embed_sharded(net, x), steps, warmup)
+            got = sharding.embed_sharded(net, x)
+            rec = {"descriptors_per_s": round(per_rank * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": per_rank * world,
+                   "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
+            if dry:            # the multi-GPU contract: gathered == single-process result over the same chunks, bit for bit, on EVERY rank
+                ref = sharding.descriptors_in_chunks(net, x, per_rank)
+                ok = torch.tensor([int(torch.equal(got, ref))])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                rec["sharded_equals_single_process_bitwise"] = bool(ok.item())
+            out["c3_gem_resnet101_ms_%s" % tag] = rec
+            del net
+        # ---- c4: augment -> embed, 128 images per rank, descriptors gathered, generator outputs not
+        per_rank, side = (2, 32) if dry else (128, 256)
+        x = synth.synth_input(5, (per_rank * world, 3, side, side), 1.0).to(dev)
+        chain = _c4_chain(dev)
+        dt = timed(lambda: sharding.embed_sharded(chain, x), steps, warmup)
+        got = sharding.embed_sharded(chain, x)
+        rec = {"images_per_s": round(per_rank * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": per_rank * world,
+               "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
+        if dry:
+            ref = sharding.descriptors_in_chunks(chain, x, per_rank)
+            ok = torch.tensor([int(torch.equal(got, ref))])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            rec["sharded_equals_single_process_bitwise"] = bool(ok.item())
+        out["c4_augment_then_embed"] = rec
+    if rank == 0:
+        print(json.dumps(out, indent=1), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def self_launch(argv, gpus):
+    """the parent never touches the GPU: it starts `python -m torch.distributed.run --nproc-per-node N bench_configs.py ...` as a CHILD
+    process and relays its output and exit code (no exec of a process that has initialised the GPU)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env, check=False).returncode
 
 
 def main():
@@ -107,6 +235,19 @@ def main():
             out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1)}
             del net
         del x
+        torch.cuda.empty_cache()
+
+        # the validate-stage caller (mdir/external/cirtorch/networks/imageretrievalnet.py:312-339): 64 database images of 3 sizes through the
+        # multi-scale + whitening network, image by image (the reference's batch-1 loop) vs equal sizes grouped into one forward per group
+        from gandtr_amd.stages.validate import extract_vectors
+        net = _c3_network(dev, True, tmp)
+        sizes = [(768, 1024), (1024, 768), (1024, 1024)]
+        imgs = [synth.synth_input(300 + i, (3,) + sizes[i % 3]).to(dev) for i in range(64)]
+        r1, ms1 = rate(lambda: extract_vectors(net, imgs, dev, batched=False), 64, steps=2, warmup=1)
+        r2, ms2 = rate(lambda: extract_vectors(net, imgs, dev, batched=True), 64, steps=2, warmup=1)
+        out["extract_vectors_64_images_3_sizes_ms_whiten"] = {"batch1_loop_descriptors_per_s": r1, "equal_sizes_batched_descriptors_per_s": r2,
+                                                               "speedup": round(r2 / r1, 2)}
+        del net, imgs
         torch.cuda.empty_cache()
 
         # c4: augment -> embed chain through CirSequentialNetwork
@@ -191,4 +332,16 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--dry-run", action="store_true", help="configs 4 / 5 sharded over N gloo ranks on the CPU, tiny images, bitwise check against one process")
+    ap.add_argument("--sharded", action="store_true", help="run the sharded configs 4 / 5 even with --gpus 1 (one rank: the same code path, RCCL world size 1)")
+    a = ap.parse_args()
+    if "RANK" in os.environ and (a.gpus > 1 or a.dry_run or a.sharded):
+        sharded_main(a)
+    elif a.gpus > 1 or a.dry_run or a.sharded:
+        sys.exit(self_launch(sys.argv[1:], max(1, a.gpus)))
+    else:
+        main()

@@ -81,15 +81,15 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
     const int nb = wrot < NBLK - 2 * NWAVE ? 3 : 2;         // blocks wrot, wrot + 4 (, wrot + 8)
 
     // the whole B operand lives in registers: fragment ks holds k = ks * 16 + fh * 8 .. +8 of output column fr
-    // (F32IN: the registers are needed for the fp4 words that wait for the second pass; the 28 KB matrix is then streamed L2 -> registers
+    // (MX: the registers are needed for the fp4 words that wait for the second pass; the 28 KB matrix is then streamed L2 -> registers
     // WRING fragments ahead, once per tile -- every wave of the chip reads the same 28 KB)
-    constexpr int NBW = F32IN ? 1 : 4 * KT, WRING = 6;
+    constexpr int NBW = MX ? 1 : 4 * KT, WRING = 6;
     f16x8 bw[NBW];
-    if (!F32IN) {
+    if (!MX) {
 #pragma unroll
         for (int ks = 0; ks < 4 * KT; ++ks) bw[ks % NBW] = *(const f16x8*)(d.w_frag + ((long)ks * 64 + lane) * 8);
     }
-    f16x8 wring[F32IN ? WRING : 1];
+    f16x8 wring[MX ? WRING : 1];
     // (uniform base + 32-bit lane offset, refreshed per tile behind an opaque copy: as 64-bit per-lane addresses the 28 + 42 fragment
     // addresses are loop invariants, which the compiler hoists out of the tile loop and spills)
     unsigned lo16 = 0, lo8 = 0, lo4 = 0;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             };
 #pragma unroll
             for (int p = 0; p < PF - 1; ++p) frags(p, afr[p]);
-            if (F32IN) {
+            if (MX) {
                 lane_offsets();
 #pragma unroll
                 for (int p = 0; p < WRING - 1; ++p) load_w(p);
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
 #pragma unroll
             for (int ks = 0; ks < 4 * KT; ++ks) {
                 if (ks + PF - 1 < 4 * KT) frags(ks + PF - 1, afr[(ks + PF - 1) % PF]);
-                if (F32IN && ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
-                const f16x8 wk = F32IN ? wring[ks % WRING] : bw[ks % NBW];
+                if (MX && ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
+                const f16x8 wk = MX ? wring[ks % WRING] : bw[ks % NBW];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], wk, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], wk, acc[1], 0, 0, 0);
                 if (MX || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);

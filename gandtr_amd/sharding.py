@@ -48,7 +48,8 @@ def embed_sharded(embed_fn, x, group=None):
     rank = dist.get_rank(group)
     lo, hi, _ = chunk_bounds(x.shape[0], world, rank)
     if hi > lo:
-        local = embed_fn(x[lo:hi]).t().contiguous()
+        local = embed_fn(x[lo:hi])
+        local = local.reshape(-1, hi - lo).t().contiguous()       # (D,) for a single image (the hub's whitening wrappers squeeze), D x n otherwise
     else:
         local = None
     d = torch.tensor([0 if local is None else local.shape[1]], device=x.device if x.is_cuda else "cpu")
@@ -56,3 +57,14 @@ def embed_sharded(embed_fn, x, group=None):
     if local is None:
         local = torch.zeros((0, int(d.item())), dtype=torch.float32, device=x.device if x.is_cuda else "cpu")
     return all_gather_descriptors(local, x.shape[0], group)
+
+
+def descriptors_in_chunks(embed_fn, x, chunk):
+    """Single-process counterpart of ``embed_sharded``: the same contiguous chunks of ``chunk`` images, one after the other, concatenated
+    to D x N.  Per-chunk shapes (hence kernel / library choices) are those of the sharded run, so the two results are equal bit for bit:
+    the multi-GPU correctness contract of SURVEY.md section 8e."""
+    cols = []
+    for lo in range(0, x.shape[0], chunk):
+        hi = min(x.shape[0], lo + chunk)
+        cols.append(embed_fn(x[lo:hi]).reshape(-1, hi - lo))
+    return torch.cat(cols, dim=1)

@@ -41,3 +41,22 @@ def test_launcher_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=False)
     assert p.returncode == 2 and b"launcher mismatch" in p.stderr
+
+
+def test_sharded_configs_4_and_5_two_ranks_dry_run():
+    """`python bench_configs.py --gpus 2 --dry-run`: BASELINE configs 4 (multi-scale GeM-ResNet-101 + lw whitening) and 5 (augment then
+    embed) sharded over two gloo ranks through the hub / wrapper / container API -- per-rank chunk, one all-gather of the descriptor block
+    (mdir/components/data/wrapper.py:197-263,308-322; mdir/learning/network.py:664-677 for the chain).  Every rank checks that the gathered
+    D x N matrix equals the single-process result over the same chunks bit for bit."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900, check=False)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    text = p.stdout.decode()
+    doc = json.loads(text[text.index("{"):])
+    assert doc["n_gpus"] == 2 and doc["backend"] == "gloo" and doc["dry_run"] is True
+    for key in ("c3_gem_resnet101_ms_hub_default", "c3_gem_resnet101_ms_sms", "c4_augment_then_embed"):
+        assert doc[key]["sharded_equals_single_process_bitwise"] is True, key
+        assert doc[key]["gathered"] == [2048, 4], key
