@@ -131,6 +131,8 @@ def kernel_name(variant):
         return "conv1x1_rb_kernel"
     if variant >= 940000:
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
+    if variant >= 935000:
+        return "conv_bneck_kernel<%d>" % (variant - 935000)
     if variant >= 930000:
         return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
     if variant >= 920000:
@@ -169,7 +171,7 @@ def conv_roofline(net, x, steps=3, traffic_key=None):
         torch.cuda.synchronize()
         for kind, variant, ms, fl in net.profile():
             all_ms += ms
-            if kind == 1:
+            if kind == 1 and fl > 0:          # (convs fused into a preceding launch -- the Bottleneck kernel -- carry no FLOPs of their own)
                 e = per.setdefault(variant, [0.0, 0.0, 0])
                 e[0] += ms; e[1] += fl; e[2] += 1
     net.set_profiling(False)

@@ -151,7 +151,8 @@ struct Step {
     bool aug;        // INPUT / CONV (f16c): the image is packed as augmented fp16 pixel words for the stem kernel's f16c form
     bool s2;         // CONV (stride 2, f16c): runs as the shift form over the virtual space-to-depth input
     int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
-    bool skip;       // MAXPOOL fused into its producer
+    bool skip;       // MAXPOOL fused into its producer; CONV: second / third conv of a fused Bottleneck (done by the first one's launch)
+    bool bneck;      // CONV: first conv of an identity Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
@@ -207,7 +208,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -414,6 +415,25 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         if (gdt_conv_pool2_eligible(d)) { plan.steps[i].pool_into = j; plan.steps[j].skip = true; }
     }
 
+    // ---- pass 2c (fp16 mode): identity Bottlenecks as one launch -- conv 1x1 (C -> MID, ReLU) -> conv 3x3 s1 p1 (MID -> MID, ReLU) -> conv 1x1
+    // (MID -> C) + residual = the first conv's input, ReLU; the two intermediate tensors have no other consumer and are never allocated
+    for (int i = 0; i + 2 < nops && !net->precision; ++i) {
+        const Op &a = ops[i], &b = ops[i + 1], &c = ops[i + 2];
+        if (a.kind != OP_CONV || b.kind != OP_CONV || c.kind != OP_CONV) continue;
+        auto plain = [&](const Op& o) { return !o.cd.transposed && !o.cd.out_f32_nchw && !o.rowsplit && o.stats_for < 0 && o.cd.stride == 1 && o.phases.size() == 1 && o.phases[0].has_frag && o.has_bias; };
+        if (!plain(a) || !plain(b) || !plain(c)) continue;
+        if (a.cd.kh != 1 || a.cd.kw != 1 || a.cd.pad != 0 || !a.cd.relu || a.res >= 0) continue;
+        if (b.cd.kh != 3 || b.cd.kw != 3 || b.cd.pad != 1 || b.cd.pad_reflect || !b.cd.relu || b.res >= 0 || b.in != a.out) continue;
+        if (c.cd.kh != 1 || c.cd.kw != 1 || c.cd.pad != 0 || !c.cd.relu || c.in != b.out || c.res != a.in) continue;
+        if (consumers[a.out] != 1 || consumers[b.out] != 1) continue;
+        if (plan.steps[i].norm_from >= 0 || plan.steps[i + 1].norm_from >= 0 || plan.steps[i + 2].norm_from >= 0) continue;
+        if (plan.steps[i].pool_into >= 0 || plan.steps[i + 1].pool_into >= 0 || plan.steps[i + 2].pool_into >= 0) continue;
+        const int C = a.cd.cin, mid = a.cd.cout;
+        if (a.cin_pad != C || a.cout_pad != mid || b.cd.cin != mid || b.cd.cout != mid || b.cout_pad != mid || c.cd.cin != mid || c.cd.cout != C || c.cout_pad != C) continue;
+        if (!gdt_bneck_eligible(C, mid, N, T[a.in].H, T[a.in].W)) continue;
+        plan.steps[i].bneck = true; plan.steps[i + 1].skip = true; plan.steps[i + 2].skip = true;
+    }
+
     // ---- pass 3: liveness + first-fit layout
     auto conv_input = [&](int i) { return plan.steps[i].norm_from >= 0 ? ops[plan.steps[i].norm_from].in : ops[i].in; };
     for (int i = 0; i < nops; ++i) {
@@ -444,6 +464,13 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             case OP_CONV: {
                 const Tensor& ti = T[o.in];       // same size as the raw tensor when the norm is folded
                 const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh);
+                if (st.skip) break;                           // (fused Bottleneck: done by the block's first conv)
+                if (st.bneck) {                               // the launch writes the block output; r and t never exist
+                    Tensor& t = T[ops[i + 2].out];
+                    t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
+                    t.off = arena.alloc(t.bytes);
+                    break;
+                }
                 if (st.pool_into >= 0) {                      // the conv writes the pooled tensor; its own output never exists
                     Tensor& t = T[ops[st.pool_into].out];
                     t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
@@ -1129,6 +1156,20 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
             }
             case OP_CONV: {
                 const Tensor& ti = T[o.in];
+                if (stp.skip) break;           // second / third conv of a fused Bottleneck
+                if (stp.bneck) {               // the whole identity Bottleneck in one launch (conv_bneck.hip)
+                    const Op &ob = net->ops[stp.op + 1], &oc = net->ops[stp.op + 2];
+                    rc = gdt_launch_bneck(tptr(o.in), tptr(oc.out), (const f16*)(net->dev_blob + o.phases[0].w_frag_off),
+                                          (const f16*)(net->dev_blob + ob.phases[0].w_frag_off), (const f16*)(net->dev_blob + oc.phases[0].w_frag_off),
+                                          (const float*)(net->dev_blob + o.bias_off), (const float*)(net->dev_blob + ob.bias_off),
+                                          (const float*)(net->dev_blob + oc.bias_off), o.cd.cin, o.cd.cout, n, ti.H, ti.W, st);
+                    if (net->profiling) {      // the block's FLOPs and time are booked on its first conv
+                        net->last_variant[stp.op] = 935000 + o.cd.cin;
+                        net->last_flops[stp.op] += net->last_flops[stp.op + 1] + net->last_flops[stp.op + 2];
+                        net->last_flops[stp.op + 1] = net->last_flops[stp.op + 2] = 0.0;
+                    }
+                    break;
+                }
                 ConvLaunch d{};
                 d.in = tptr(o.in);
                 if (stp.norm_from >= 0) {      // InstanceNorm(+ReLU) of the producer applied while staging the input

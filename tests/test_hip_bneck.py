@@ -1,0 +1,75 @@
+"""GPU parity of the fused identity Bottleneck (conv_bneck.hip: conv 1x1 -> 3x3 -> 1x1 + residual, torchvision's Bottleneck as restated in
+oracle/gandtr_oracle.py:116-133, one launch; ResNet-101 layer1 / layer2 shapes) against an fp64 evaluation of the same block on the same
+fp16-rounded input with the two intermediate tensors rounded to fp16 where the kernel stores them; against the layer-by-layer kernels of
+the same build; image borders (the 3x3 conv zero-pads r, not x); and that the fused kernel is the one that ran."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gandtr_amd.engine import HipNet
+from gandtr_amd.tools import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(name, shape, std):
+    return synth._normal(0, name, shape, std)
+
+
+def _block_net(dev, C, mid, nblocks=1):
+    net = HipNet(dev, "f16")
+    t = net.input(3)
+    x = net.conv(t, _g("w0", (C, 3, 1, 1), 0.5), _g("b0", (C,), 0.3), relu=True)
+    taps, ws = [net.output_nchw(x)], []
+    for b in range(nblocks):
+        wr, br = _g("wr%d" % b, (mid, C, 1, 1), C ** -0.5), _g("br%d" % b, (mid,), 0.2)
+        w3, b3 = _g("w3%d" % b, (mid, mid, 3, 3), (9 * mid) ** -0.5), _g("b3%d" % b, (mid,), 0.2)
+        we, be = _g("we%d" % b, (C, mid, 1, 1), mid ** -0.5), _g("be%d" % b, (C,), 0.2)
+        r = net.conv(x, wr, br, relu=True)
+        t3 = net.conv(r, w3, b3, pad=1, relu=True)
+        x = net.conv(t3, we, be, relu=True, residual=x)
+        taps.append(net.output_nchw(x))
+        ws.append((wr, br, w3, b3, we, be))
+    net.finalize()
+    return net, taps, ws
+
+
+def _ref_block(x, w):
+    wr, br, w3, b3, we, be = (a.double() for a in w)
+    r = F.relu(F.conv2d(x, wr, br)).half().double()                     # the kernel keeps r and t in LDS as fp16
+    t = F.relu(F.conv2d(r, w3, b3, padding=1)).half().double()
+    return F.relu(F.conv2d(t, we, be) + x)
+
+
+@pytest.mark.parametrize("C,mid,n,h,w", [(256, 64, 4, 128, 128), (512, 128, 4, 64, 128), (256, 64, 1, 256, 256)])
+def test_fused_bottleneck(cuda_device, C, mid, n, h, w, monkeypatch):
+    net, taps, ws = _block_net(cuda_device, C, mid, nblocks=2)
+    x = synth.synth_input(5, (n, 3, h, w))
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    variants = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert variants.count(935000 + C) == 2, variants                  # both blocks ran as one launch each
+    xin = outs[taps[0]].double().cpu()
+    ref1 = _ref_block(xin, ws[0])
+    got1 = outs[taps[1]].double().cpu()
+    err1 = float((got1 - ref1).abs().max() / ref1.abs().max())
+    ref2 = _ref_block(got1, ws[1])                                      # second block on the first one's actual (fp16) output
+    got2 = outs[taps[2]].double().cpu()
+    err2 = float((got2 - ref2).abs().max() / ref2.abs().max())
+    print("fused bottleneck C %d mid %d: %.2e, %.2e of fp64 (fp16 output rounding 4.9e-4)" % (C, mid, err1, err2))
+    assert err1 < 1.5e-3 and err2 < 1.5e-3, (err1, err2)
+    # the image border rows / columns, where the r halo is zero padding
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), h - 1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), w - 1)):
+        assert float((got1[sl] - ref1[sl]).abs().max() / ref1.abs().max()) < 1.5e-3
+    assert torch.equal(outs[taps[2]], net.forward(x.to(cuda_device))[taps[2]])       # deterministic
+    # against the layer-by-layer kernels of the same build (another summation order and one more rounding point: not bitwise)
+    monkeypatch.setenv("GDT_CONV_BNECK", "0")                           # read when a net plans a geometry
+    net2, taps2, _ = _block_net(cuda_device, C, mid, nblocks=2)
+    net2.set_profiling(True)
+    outs2 = net2.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert (935000 + C) not in [v for k, v, ms, fl in net2.profile() if k == 1]
+    d = float((outs2[taps2[2]].double() - outs[taps[2]].double()).abs().max() / ref2.abs().max())
+    assert d < 2e-3, d
