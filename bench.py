@@ -92,6 +92,9 @@ class ClockSampler:
                 "power_cap_w": round(cap / 1e6, 1) if cap else None, "samples": len(mhz)}
 
 
+LAST_EVENT_MS = [None]
+
+
 def timed(fn, steps, warmup, dev, distributed):
     for _ in range(warmup):
         fn()
@@ -99,14 +102,18 @@ def timed(fn, steps, warmup, dev, distributed):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()                      # (the library launches on torch's current stream: the events bracket exactly the timed launches)
     for _ in range(steps):
         fn()
+    e1.record()
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    LAST_EVENT_MS[0] = e0.elapsed_time(e1) / steps     # hipEventElapsedTime cross-check of the wall-clock figure
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -131,8 +138,8 @@ def kernel_name(variant):
         return "conv1x1_rb_kernel"
     if variant >= 940000:
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
-    if variant >= 935000:
-        return "conv_bneck_kernel<%d>" % (variant - 935000)
+    if variant >= 935000:                                   # (+1: the projection-shortcut form)
+        return "conv_bneck_kernel<%d>%s" % ((variant - 935000) & ~1, "[projection]" if (variant & 1) else "")
     if variant >= 930000:
         return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
     if variant >= 920000:
@@ -353,6 +360,7 @@ def main():
             dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
     else:
         dt = timed(lambda: gen.forward(xg), a.steps, a.warmup, dev, distributed)
+    gen_event_ms = LAST_EVENT_MS[0]
     mfma_only = None
     if rank == 0:          # sustained rate of the fp16 matrix pipe alone on this very device, measured right after the timed region
         try:
@@ -365,7 +373,7 @@ def main():
             print("mfma-only measurement failed: %r" % (exc,), file=sys.stderr)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
-    roof = conv_roofline(gen, xg, traffic_key="r02_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    roof = conv_roofline(gen, xg, traffic_key="r03_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
     if roof is not None:
         # the kernel issues 1.5 MFMA-slots per algorithmic fp16 one (1 fp16 + 1/2 block-scaled): its matrix pipe work is 1.5 x `achieved`
         roof["mfma_work_factor"] = 1.5
@@ -446,6 +454,7 @@ def main():
                            "precision": "f16c: fp32 NHWC activations; conv = fp16 MFMA product (fp32 accumulate) + block-scaled fp4 x fp6 "
                                         "correction MFMA carrying both fp16 rounding residuals; layers without a compensated kernel run the "
                                         "three-pass f16x3 split"},
+                "ms_per_step_hip_events": None if gen_event_ms is None else round(gen_event_ms, 3),
                 "whole_net_tflops_per_gpu": round(gen_tflops, 1),
                 "parity": "north_star gates met by this mode: generator max|d|/max|ref| <= 1e-3 at every tap and pre-tanh -- measured against the "
                           "CPU oracle: 4.6e-4 ... 4.9e-4 pre-tanh at batch 64 (taps 7e-5 ... 1.5e-4), image max|d| 6.6e-4 / 7.2e-4 absolute at "

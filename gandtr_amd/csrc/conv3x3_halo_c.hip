@@ -46,6 +46,9 @@
 #ifndef GDT_C_NT
 #define GDT_C_NT 0
 #endif
+#ifndef GDT_C_WB_INTERIOR
+#define GDT_C_WB_INTERIOR 0     // 1: write-back stores of the folded norm only for the patch's interior pixels (exec-masked stores)
+#endif
 #ifndef GDT_C_SCHED
 #define GDT_C_SCHED 2          // 1: loads after each column's MFMAs (clumped)   2: one load per two MFMAs (+0.3 % images/s)
 #endif
@@ -208,8 +211,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         // write-back of the transformed tensor (every piece stores the value of its clamped source pixel: identical bits from
         // neighbouring patches, no branch)
         if (WB && !(GDT_C_ABL & 16)) {
+#if GDT_C_WB_INTERIOR
+            // only the patch's own 16 x 16 pixels: the halo ring belongs to the neighbours, who write identical bits (27 % of the stores)
+            if ((unsigned)(phy - 1) < 16u && (unsigned)(phx - 1) < 16u) {
+                *(float4*)((char*)wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
+                *(float4*)((char*)wbf + p.goff + 16) = make_float4(a[4], a[5], a[6], a[7]);
+            }
+#else
             *(float4*)((char*)wbf + p.goff) = make_float4(a[0], a[1], a[2], a[3]);
             *(float4*)((char*)wbf + p.goff + 16) = make_float4(a[4], a[5], a[6], a[7]);
+#endif
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = p.ok ? a[e] : 0.f;

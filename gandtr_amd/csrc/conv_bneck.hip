@@ -48,25 +48,28 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int C, int MID, int PH>
+// DS: the block's shortcut is a 1x1 projection W_d (CIN -> C, BatchNorm folded) of x instead of x itself -- layer1's first block (CIN 64): the x halo
+// chunk stays in LDS through the expand phase, which accumulates W_d x into the same accumulators as W_e t (K = MID + CIN), r and t get regions of their own.
+template <int C, int MID, int PH, int CIN = C, bool DS = false>
 struct Geo {
     static constexpr int HH = PH + 2, HPIX = HH * HW_, HB = (HPIX + 31) / 32, HPAD = HB * 32;     // halo pixels, 32-pixel blocks
     static constexpr int P = PH * PW, PB = P / 32;                 // output pixels, 32-pixel blocks (a block = two patch rows)
-    static constexpr int NC = C / 64, MB = MID / 32, MP = MID / 64;                                 // x chunks, mid 32-blocks, mid 64-planes
+    static constexpr int NC = CIN / 64, MB = MID / 32, MP = MID / 64;                                 // x chunks, mid 32-blocks, mid 64-planes
     static constexpr int XBYTES = HPAD * 128;                      // one x chunk buffer (64 channels x fp16 per halo pixel)
     static constexpr int NPX = (XBYTES / 16 + NT - 1) / NT;        // 16-byte units of a chunk per thread
     static constexpr int RBYTES = MP * HPAD * 128;                 // r halo, MP planes of 128-byte rows: over the x buffers
     static constexpr int TBYTES = MP * P * 128;                    // t: over x buffer 1 where r leaves it free (layer1), else its own region
-    static constexpr bool T_OVER_X = RBYTES + TBYTES <= 2 * XBYTES;
+    static constexpr bool T_OVER_X = !DS && RBYTES + TBYTES <= 2 * XBYTES;
     static constexpr int W3BYTES = 9 * MID * MID * 2;              // W_3: resident in LDS when it fits beside the two x buffers (layer1: to the byte) ...
-    static constexpr bool W3_RES = 2 * XBYTES + W3BYTES <= 160 * 1024 && RBYTES + TBYTES <= 2 * XBYTES;
+    static constexpr bool W3_RES = !DS && 2 * XBYTES + W3BYTES <= 160 * 1024 && RBYTES + TBYTES <= 2 * XBYTES;
     static constexpr int W3P = MID * MID * 2, NW3 = 9;             // ... else staged tap by tap, two buffers
     static constexpr int NPW = W3_RES ? 1 : W3P / 16 / NT;         // 16-byte units of a tap per thread
+    static constexpr int R_OFF = DS ? XBYTES : 0;                  // (DS: x buffer 0 keeps the chunk, r lives in buffer 1's place)
     static constexpr int T_OFF = T_OVER_X ? RBYTES : 2 * XBYTES;
     static constexpr int W3_OFF = 2 * XBYTES + (T_OVER_X ? 0 : TBYTES);
     static constexpr int LDS = W3_OFF + (W3_RES ? W3BYTES : 2 * W3P);
     static constexpr int ECP = C / 64, EPW = (ECP * PB) / NWAVE;   // expand: 64-channel pairs; (pair, pixel block) tiles per wave
-    static_assert(RBYTES <= 2 * XBYTES && NWAVE * 4096 <= RBYTES && LDS <= 160 * 1024 && (W3_RES || W3P % (16 * NT) == 0), "LDS layout");
+    static_assert((!DS || (NC == 1 && RBYTES <= XBYTES)) && RBYTES <= 2 * XBYTES && NWAVE * 4096 <= RBYTES && LDS <= 160 * 1024 && (W3_RES || W3P % (16 * NT) == 0), "LDS layout");
     static_assert((NWAVE / MB) * 3 >= HB, "reduce tiles: 3 pixel blocks per wave");
     static_assert(PB * MB == 2 * NWAVE, "3x3 tiles: two per wave");
     static_assert(ECP <= NWAVE ? (NWAVE % ECP == 0 && PB % (NWAVE / ECP) == 0) : false, "expand tiles");
@@ -77,16 +80,17 @@ struct BneckLaunch {
     const f16* x; f16* y;
     const f16* wr; const f16* w3; const f16* we;         // fragment order [cout/32][K/16][64 lanes][8 halves]
     const float* br; const float* b3; const float* be;   // folded BatchNorm shifts
+    const f16* wd; const float* bd;                      // projection shortcut (DS form), else null
     int N, H, W;
 };
 
-template <int C, int MID, int PH>
+template <int C, int MID, int PH, int CIN = C, bool DS = false>
 __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, const int ntiles) {
-    using G = Geo<C, MID, PH>;
+    using G = Geo<C, MID, PH, CIN, DS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbuf0 = smem;
     char* const xbuf1 = smem + G::XBYTES;
-    char* const rbuf = smem;                       // (over the x buffers, once the reduce phase has consumed them)
+    char* const rbuf = smem + G::R_OFF;            // (over the x buffers, once the reduce phase has consumed them; DS: beside the kept chunk)
     char* const tbuf = smem + G::T_OFF;
     char* const w3s = smem + G::W3_OFF;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
             const int hp = min(e >> 3, G::HPIX - 1);
             const int hy = hp / HW_, hx = hp - hy * HW_;
             const int iy = min(max(y0 - 1 + hy, 0), d.H - 1), ix = min(max(x0 - 1 + hx, 0), d.W - 1);
-            xr.v[k] = *(const f16x8*)(d.x + ((size_t)((n * d.H + iy) * d.W + ix) * C + c * 64 + (e & 7) * 8));
+            xr.v[k] = *(const f16x8*)(d.x + ((size_t)((n * d.H + iy) * d.W + ix) * CIN + c * 64 + (e & 7) * 8));
         }
     };
     auto store_x = [&](const XRegs& xr, char* dst) {
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
 
     XRegs xa, xb;                  // chunk c + 1 / c + 2 of the stream (roles alternate)
     load_x(tile, 0, xa);
-    load_x(tile, 1, xb);
+    if (G::NC > 1) load_x(tile, 1, xb);
     store_x(xa, xbuf0);
     lds_barrier();
 
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
         WRegs wq0, wq1;                                              // W_3 pieces 0 and 1: requested under the last two chunks
         f16x8 wrn[4];                                                // (W_r from L2: the fragments of the NEXT chunk, requested one chunk ahead)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wrn[ks] = *(const f16x8*)((const char*)d.wr + ((rmb * (C / 16) + ks) << 10) + lo16);
+        for (int ks = 0; ks < 4; ++ks) wrn[ks] = *(const f16x8*)((const char*)d.wr + ((rmb * (CIN / 16) + ks) << 10) + lo16);
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
             XRegs& xin = (c & 1) ? xa : xb;                          // holds chunk c + 1
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
             for (int ks = 0; ks < 4; ++ks) wrc[ks] = wrn[ks];
             if (c + 1 < G::NC) {                                     // weight loads first: older than this iteration's HBM loads
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wrn[ks] = *(const f16x8*)((const char*)d.wr + ((rmb * (C / 16) + (c + 1) * 4 + ks) << 10) + lo16);
+                for (int ks = 0; ks < 4; ++ks) wrn[ks] = *(const f16x8*)((const char*)d.wr + ((rmb * (CIN / 16) + (c + 1) * 4 + ks) << 10) + lo16);
             }
-            if (!G::W3_RES && c == G::NC - 2) load_w3(0, wq0);
+            if (!G::W3_RES && (c == G::NC - 2 || G::NC == 1)) load_w3(0, wq0);
             if (!G::W3_RES && c == G::NC - 1) load_w3(1, wq1);
             if (c + 2 < G::NC) load_x(tile, c + 2, xld);
             const char* xbc = (c & 1) ? xbuf1 : xbuf0;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
         BN_STAMP(0)
         // the first two x chunks of the NEXT patch and the residual rows of this one are requested now: the memory system works through
         // the 3x3 phase, which itself touches LDS only (layer1) / L2 only (layer2's W_3 taps, which queue behind these loads once)
-        if (has_next) { load_x(next, 0, xa); load_x(next, 1, xb); }
+        if (has_next) { load_x(next, 0, xa); if (G::NC > 1) load_x(next, 1, xb); }
         const int pl = lane >> 3, pc = lane & 7;
         auto res_off = [&](int jb, int i) -> size_t {           // row this lane stores / fetches the residual of: output pixel 8 i + (lane >> 3) of
             const int prow = (epb0 + jb) * 32 + 8 * i + pl;     // pixel block epb0 + jb (patch row prow / 16, column prow % 16), 16-byte piece lane & 7
@@ -360,15 +364,31 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bev[j][g] = bias4(d.be, ecp * 64 + j * 32, g, fh);
             f16x8 res[2][4];                                           // residual rows: block jb in res[jb & 1], block jb + 1 requested meanwhile
+            if (!DS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) res[0][i] = *(const f16x8*)(d.x + res_off(0, i));
+                for (int i = 0; i < 4; ++i) res[0][i] = *(const f16x8*)(d.x + res_off(0, i));
+            }
+            f16x8 wdf[2][DS ? CIN / 16 : 1];                           // (DS) the wave's W_d fragments
+            if (DS) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kg = 0; kg < CIN / 16; ++kg) wdf[j][kg] = *(const f16x8*)((const char*)d.wd + (((ecp * 2 + j) * (CIN / 16) + kg) << 10) + lo16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b2 = bias4(d.bd, ecp * 64 + j * 32, g, fh);
+                        bev[j][g].x += b2.x; bev[j][g].y += b2.y; bev[j][g].z += b2.z; bev[j][g].w += b2.w;
+                    }
+            }
 #pragma unroll
             for (int jb = 0; jb < G::EPW; ++jb) {
                 const int epb = epb0 + jb;
                 size_t goff[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) goff[i] = res_off(jb, i);
-                if (jb + 1 < G::EPW) {
+                if (!DS && jb + 1 < G::EPW) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) res[(jb + 1) & 1][i] = *(const f16x8*)(d.x + res_off(jb + 1, i));
                 }
@@ -383,6 +403,15 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
                     const f16x8 tf = *(const f16x8*)(tbuf + (kg >> 2) * (G::P * 128) + row * 128 + (((2 * (kg & 3) + fh) ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) eacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wef[j][kg], tf, eacc[j], 0, 0, 0);
+                }
+                if (DS) {                    // + W_d x: the pixel's own row of the x halo chunk kept in buffer 0
+                    const int hrow = ((row >> 4) + 1) * HW_ + (row & 15) + 1;
+#pragma unroll
+                    for (int kg = 0; kg < CIN / 16; ++kg) {
+                        const f16x8 xf = *(const f16x8*)(xbuf0 + hrow * 128 + (((2 * kg + fh) ^ ((hrow >> 1) & 7)) << 4));
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) eacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wdf[j][kg], xf, eacc[j], 0, 0, 0);
+                    }
                 }
                 // accumulators (+ bias) -> patch: lane holds pixel fr, channels j * 32 + 8 g + 4 fh + {0..3} of the pair
 #pragma unroll
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
                     const f16x8 v = *(const f16x8*)(patch + pr * 128 + ((pc ^ (pr & 7)) << 4));
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf((float)v[e] + (float)res[jb & 1][i][e], 0.f);
+                    for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf((float)v[e] + (DS ? 0.f : (float)res[jb & 1][i][e]), 0.f);
                     *(f16x8*)(d.y + goff[i]) = o;
                 }
             }
@@ -420,16 +449,16 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
 #endif
 }
 
-template <int C, int MID, int PH>
+template <int C, int MID, int PH, int CIN = C, bool DS = false>
 int launch(const BneckLaunch& d, hipStream_t stream) {
-    using G = Geo<C, MID, PH>;
+    using G = Geo<C, MID, PH, CIN, DS>;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH, CIN, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
     }
     const int ntiles = d.N * (d.W / PW) * (d.H / PH);
     const int grid = min(cus, (ntiles + 7) / 8 * 8);
@@ -439,7 +468,7 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
     if (!sb) GDT_CHECK_HIP(hipMalloc((void**)&sb, (size_t)cus * NWAVE * 4 * 8));
     BneckLaunch ds = d; ds.stamps = sb;
     GDT_CHECK_HIP(hipMemsetAsync(sb, 0, (size_t)cus * NWAVE * 4 * 8, stream));
-    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH>), dim3(grid), dim3(NT), G::LDS, stream, ds, ntiles);
+    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS>), dim3(grid), dim3(NT), G::LDS, stream, ds, ntiles);
     if (++calls % 50 < 3) {
         GDT_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)grid * NWAVE * 4);
@@ -452,7 +481,7 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
     }
     return GDT_OK;
 #endif
-    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH>), dim3(grid), dim3(NT), G::LDS, stream, d, ntiles);
+    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS>), dim3(grid), dim3(NT), G::LDS, stream, d, ntiles);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -461,12 +490,12 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
 
 // Eligible: the three convs of an identity Bottleneck (checked by the planner in net.hip) with (C, MID) = (256, 64) or (512, 128), maps that
 // the patches tile exactly, enough patches to fill the chip, offsets within 32 bits.
-bool gdt_bneck_eligible(int C, int mid, int N, int H, int W) {
+bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W) {
     const char* e = getenv("GDT_CONV_BNECK");          // 0: off (read at plan time, once per net and geometry: A/B inside one process)
     if (e && atoi(e) == 0) return false;
     int ph = 0;
-    if (C == 256 && mid == 64) ph = 16;
-    else if (C == 512 && mid == 128) ph = 8;
+    if (C == 256 && mid == 64 && (cin == 256 || cin == 64)) ph = 16;        // cin 64: the projection-shortcut form (layer1's first block)
+    else if (C == 512 && mid == 128 && cin == 512) ph = 8;
     else return false;
     if (H % ph != 0 || W % PW != 0) return false;
     if ((long)N * H * W * C >= (1L << 31)) return false;
@@ -474,10 +503,11 @@ bool gdt_bneck_eligible(int C, int mid, int N, int H, int W) {
 }
 
 int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
-                     int C, int mid, int N, int H, int W, hipStream_t stream) {
-    BneckLaunch d{nullptr, x, y, wr, w3, we, br, b3, be, N, H, W};
-    if (C == 256 && mid == 64) return launch<256, 64, 16>(d, stream);
-    if (C == 512 && mid == 128) return launch<512, 128, 8>(d, stream);
+                     const f16* wd, const float* bd, int cin, int C, int mid, int N, int H, int W, hipStream_t stream) {
+    BneckLaunch d{nullptr, x, y, wr, w3, we, br, b3, be, wd, bd, N, H, W};
+    if (cin == 256 && C == 256 && mid == 64 && !wd) return launch<256, 64, 16>(d, stream);
+    if (cin == 512 && C == 512 && mid == 128 && !wd) return launch<512, 128, 8>(d, stream);
+    if (cin == 64 && C == 256 && mid == 64 && wd && bd) return launch<256, 64, 16, 64, true>(d, stream);
     gdt_set_error("gdt_launch_bneck: unsupported shape");
     return GDT_ERR_INVALID;
 }

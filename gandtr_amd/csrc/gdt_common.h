@@ -146,7 +146,7 @@ bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed fo
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d, hipStream_t stream);
-bool gdt_bneck_eligible(int C, int mid, int N, int H, int W);   // conv_bneck.hip: identity Bottleneck (1x1 -> 3x3 -> 1x1 + residual) as one launch (variant 935000 + C)
+bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W);   // conv_bneck.hip: Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut) as one launch (variant 935000 + C)
 int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
-                     int C, int mid, int N, int H, int W, hipStream_t stream);
+                     const f16* wd, const float* bd, int cin, int C, int mid, int N, int H, int W, hipStream_t stream);   // wd / bd: 1x1 projection shortcut (cin != C), else null
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

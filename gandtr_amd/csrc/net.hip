@@ -152,7 +152,9 @@ struct Step {
     bool s2;         // CONV (stride 2, f16c): runs as the shift form over the virtual space-to-depth input
     int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
     bool skip;       // MAXPOOL fused into its producer; CONV: second / third conv of a fused Bottleneck (done by the first one's launch)
-    bool bneck;      // CONV: first conv of an identity Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2
+    bool bneck;      // CONV: first conv of a Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2 (identity shortcut) ...
+    int bneck_ds;    // ... or {reduce, 1x1 projection shortcut} in either order at i, i + 1 (bneck_a / bneck_ds), i + 2 (3x3), i + 3 (expand + shortcut); -1: identity form
+    int bneck_a;     // index of the block's reduce conv (identity form: the step itself)
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
@@ -208,7 +210,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -430,8 +432,33 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         if (plan.steps[i].pool_into >= 0 || plan.steps[i + 1].pool_into >= 0 || plan.steps[i + 2].pool_into >= 0) continue;
         const int C = a.cd.cin, mid = a.cd.cout;
         if (a.cin_pad != C || a.cout_pad != mid || b.cd.cin != mid || b.cd.cout != mid || b.cout_pad != mid || c.cd.cin != mid || c.cd.cout != C || c.cout_pad != C) continue;
-        if (!gdt_bneck_eligible(C, mid, N, T[a.in].H, T[a.in].W)) continue;
+        if (!gdt_bneck_eligible(C, C, mid, N, T[a.in].H, T[a.in].W)) continue;
         plan.steps[i].bneck = true; plan.steps[i + 1].skip = true; plan.steps[i + 2].skip = true;
+    }
+    // ... and the projection-shortcut form (first block of a stage at stride 1): conv 1x1 (CIN -> MID, ReLU), conv 1x1 (CIN -> C, no ReLU: the shortcut,
+    // same input), conv 3x3, conv 1x1 (MID -> C) + shortcut, ReLU
+    for (int i = 0; i + 3 < nops && !net->precision; ++i) {
+        if (ops[i].kind != OP_CONV || ops[i + 1].kind != OP_CONV) continue;
+        const bool ds_first = !ops[i].cd.relu;                   // (the shortcut projection has no ReLU; engine.py emits it before the reduce conv)
+        const int ia = ds_first ? i + 1 : i, ids = ds_first ? i : i + 1;
+        const Op &a = ops[ia], &ds = ops[ids], &b = ops[i + 2], &c = ops[i + 3];
+        if (a.kind != OP_CONV || ds.kind != OP_CONV || b.kind != OP_CONV || c.kind != OP_CONV) continue;
+        auto plain = [&](const Op& o) { return !o.cd.transposed && !o.cd.out_f32_nchw && !o.rowsplit && o.stats_for < 0 && o.cd.stride == 1 && o.phases.size() == 1 && o.phases[0].has_frag && o.has_bias; };
+        if (!plain(a) || !plain(ds) || !plain(b) || !plain(c)) continue;
+        if (a.cd.kh != 1 || a.cd.kw != 1 || a.cd.pad != 0 || !a.cd.relu || a.res >= 0) continue;
+        if (ds.cd.kh != 1 || ds.cd.kw != 1 || ds.cd.pad != 0 || ds.cd.relu || ds.res >= 0 || ds.in != a.in) continue;
+        if (b.cd.kh != 3 || b.cd.kw != 3 || b.cd.pad != 1 || b.cd.pad_reflect || !b.cd.relu || b.res >= 0 || b.in != a.out) continue;
+        if (c.cd.kh != 1 || c.cd.kw != 1 || c.cd.pad != 0 || !c.cd.relu || c.in != b.out || c.res != ds.out) continue;
+        if (consumers[a.out] != 1 || consumers[b.out] != 1 || consumers[ds.out] != 1) continue;
+        bool folded = false;
+        for (int k = i; k < i + 4; ++k) folded = folded || plan.steps[k].norm_from >= 0 || plan.steps[k].pool_into >= 0 || plan.steps[k].skip || plan.steps[k].bneck;
+        if (folded) continue;
+        const int cin = a.cd.cin, mid = a.cd.cout, C = c.cd.cout;
+        if (a.cin_pad != cin || a.cout_pad != mid || ds.cd.cin != cin || ds.cin_pad != cin || ds.cd.cout != C || ds.cout_pad != C || b.cd.cin != mid || b.cd.cout != mid ||
+            b.cout_pad != mid || c.cd.cin != mid || c.cout_pad != C || cin == C) continue;
+        if (!gdt_bneck_eligible(cin, C, mid, N, T[a.in].H, T[a.in].W)) continue;
+        plan.steps[i].bneck = true; plan.steps[i].bneck_ds = ids; plan.steps[i].bneck_a = ia;
+        plan.steps[i + 1].skip = true; plan.steps[i + 2].skip = true; plan.steps[i + 3].skip = true;
     }
 
     // ---- pass 3: liveness + first-fit layout
@@ -465,8 +492,8 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
                 const Tensor& ti = T[o.in];       // same size as the raw tensor when the norm is folded
                 const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh);
                 if (st.skip) break;                           // (fused Bottleneck: done by the block's first conv)
-                if (st.bneck) {                               // the launch writes the block output; r and t never exist
-                    Tensor& t = T[ops[i + 2].out];
+                if (st.bneck) {                               // the launch writes the block output; r and t (and the projected shortcut) never exist
+                    Tensor& t = T[ops[i + (st.bneck_ds >= 0 ? 3 : 2)].out];
                     t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
                     t.off = arena.alloc(t.bytes);
                     break;
@@ -1157,16 +1184,19 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
             case OP_CONV: {
                 const Tensor& ti = T[o.in];
                 if (stp.skip) break;           // second / third conv of a fused Bottleneck
-                if (stp.bneck) {               // the whole identity Bottleneck in one launch (conv_bneck.hip)
-                    const Op &ob = net->ops[stp.op + 1], &oc = net->ops[stp.op + 2];
-                    rc = gdt_launch_bneck(tptr(o.in), tptr(oc.out), (const f16*)(net->dev_blob + o.phases[0].w_frag_off),
+                if (stp.bneck) {               // the whole Bottleneck in one launch (conv_bneck.hip)
+                    const bool dsf = stp.bneck_ds >= 0;
+                    const Op &oa = net->ops[stp.bneck_a], &ob = net->ops[stp.op + (dsf ? 2 : 1)], &oc = net->ops[stp.op + (dsf ? 3 : 2)];
+                    const Op* od = dsf ? &net->ops[stp.bneck_ds] : nullptr;
+                    rc = gdt_launch_bneck(tptr(oa.in), tptr(oc.out), (const f16*)(net->dev_blob + oa.phases[0].w_frag_off),
                                           (const f16*)(net->dev_blob + ob.phases[0].w_frag_off), (const f16*)(net->dev_blob + oc.phases[0].w_frag_off),
-                                          (const float*)(net->dev_blob + o.bias_off), (const float*)(net->dev_blob + ob.bias_off),
-                                          (const float*)(net->dev_blob + oc.bias_off), o.cd.cin, o.cd.cout, n, ti.H, ti.W, st);
+                                          (const float*)(net->dev_blob + oa.bias_off), (const float*)(net->dev_blob + ob.bias_off),
+                                          (const float*)(net->dev_blob + oc.bias_off),
+                                          od ? (const f16*)(net->dev_blob + od->phases[0].w_frag_off) : nullptr, od ? (const float*)(net->dev_blob + od->bias_off) : nullptr,
+                                          oa.cd.cin, oc.cd.cout, oa.cd.cout, n, T[oa.in].H, T[oa.in].W, st);
                     if (net->profiling) {      // the block's FLOPs and time are booked on its first conv
-                        net->last_variant[stp.op] = 935000 + o.cd.cin;
-                        net->last_flops[stp.op] += net->last_flops[stp.op + 1] + net->last_flops[stp.op + 2];
-                        net->last_flops[stp.op + 1] = net->last_flops[stp.op + 2] = 0.0;
+                        net->last_variant[stp.op] = 935000 + oc.cd.cout + (dsf ? 1 : 0);
+                        for (int k = 1; k <= (dsf ? 3 : 2); ++k) { net->last_flops[stp.op] += net->last_flops[stp.op + k]; net->last_flops[stp.op + k] = 0.0; }
                     }
                     break;
                 }

@@ -73,3 +73,42 @@ def test_fused_bottleneck(cuda_device, C, mid, n, h, w, monkeypatch):
     assert (935000 + C) not in [v for k, v, ms, fl in net2.profile() if k == 1]
     d = float((outs2[taps2[2]].double() - outs[taps[2]].double()).abs().max() / ref2.abs().max())
     assert d < 2e-3, d
+
+
+@pytest.mark.parametrize("projection_first", [True, False])
+def test_fused_bottleneck_projection_shortcut(cuda_device, projection_first):
+    """layer1's first block: 64 -> (64, 64) -> 256 with a 1x1 projection of the input as the shortcut (torchvision `downsample`); the
+    projection is emitted before the reduce conv by engine.py (either order is recognised) -- one launch, against fp64"""
+    C, cin, mid, n, h, w = 256, 64, 64, 4, 128, 128
+    net = HipNet(cuda_device, "f16")
+    t = net.input(3)
+    x = net.conv(t, _g("w0", (cin, 3, 1, 1), 0.5), _g("b0", (cin,), 0.3), relu=True)
+    wr, br = _g("wr", (mid, cin, 1, 1), cin ** -0.5), _g("br", (mid,), 0.2)
+    wd, bd = _g("wd", (C, cin, 1, 1), cin ** -0.5), _g("bd", (C,), 0.2)
+    w3, b3 = _g("w3", (mid, mid, 3, 3), (9 * mid) ** -0.5), _g("b3", (mid,), 0.2)
+    we, be = _g("we", (C, mid, 1, 1), mid ** -0.5), _g("be", (C,), 0.2)
+    if projection_first:
+        sc = net.conv(x, wd, bd)
+        r = net.conv(x, wr, br, relu=True)
+    else:
+        r = net.conv(x, wr, br, relu=True)
+        sc = net.conv(x, wd, bd)
+    t3 = net.conv(r, w3, b3, pad=1, relu=True)
+    y = net.conv(t3, we, be, relu=True, residual=sc)
+    taps = [net.output_nchw(x), net.output_nchw(y)]
+    net.finalize()
+    xi = synth.synth_input(6, (n, 3, h, w))
+    net.set_profiling(True)
+    outs = net.forward(xi.to(cuda_device))
+    torch.cuda.synchronize()
+    variants = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert 935000 + C + 1 in variants, variants
+    xin = outs[taps[0]].double().cpu()
+    rr = F.relu(F.conv2d(xin, wr.double(), br.double())).half().double()
+    tt = F.relu(F.conv2d(rr, w3.double(), b3.double(), padding=1)).half().double()
+    ref = F.relu(F.conv2d(tt, we.double(), be.double()) + F.conv2d(xin, wd.double(), bd.double()))
+    got = outs[taps[1]].double().cpu()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print("fused bottleneck with projection shortcut: %.2e of fp64" % err)
+    assert err < 1.5e-3, err
+    assert torch.equal(outs[taps[1]], net.forward(xi.to(cuda_device))[taps[1]])

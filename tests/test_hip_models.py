@@ -59,9 +59,9 @@ def test_generator_tiny_all_taps_f16_envelope(cuda_device, norm):
 @pytest.mark.parametrize("batch", [2, 8])
 def test_generator_full_pre_tanh(cuda_device, norm, gain, batch):
     """Full-size ResnetGenerator (ngf 64, 9 blocks) on Nx3x256x256 in the default precision: every tap and the pre-tanh output
-    (tap 26) within north_star's 1e-3.  Batch 8 is the smallest batch at which the compensated patch kernels (conv3x3_halo_c.hip,
-    3x3 and transposed forms, InstanceNorm folded into their staging) take the resblock / up-sampling layers; batch 2 runs the
-    generic f16x3 kernels throughout."""
+    (tap 26) within north_star's 1e-3.  Both batches run the compensated patch kernels (conv3x3_halo_c.hip: eligible from 16 patch
+    tiles up, `min_tiles` in gdt_conv_halo_c_eligible; batch 2 at 256^2 = 32 tiles, in the 128-column form below 192 tiles) with the
+    InstanceNorms folded into their staging; only batch 1 at small images falls back to the generic f16x3 kernels."""
     from gandtr_amd.engine import build_generator
     sd = synth.generator_state(0, norm, gain=gain or 0.02)
     x = synth.synth_input(2, (batch, 3, 256, 256), 1.0)
