@@ -883,7 +883,7 @@ bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
     const int cr = d.Cin >> 2;
     if ((cr != 64 && cr != 128) || d.ntaps != 4 || d.TW != 2 || d.Kpad != 4 * d.Cin || d.CoutPad % 128 != 0 || d.Cout % 8 != 0) return false;
     if (d.OH != (d.H - 1) / 2 + 1 || d.OW != (d.W - 1) / 2 + 1) return false;
-    if ((d.in_res || d.in_out) && !d.in_norm) return false;
+    if (d.in_res || (d.in_out && !d.in_norm)) return false;      // no residual mode in the stride-2 launch: a residual would be dropped silently
     if (d.stats && ((d.OH & 15) || (d.OW & 15))) return false;
     if ((long)d.N * d.H * d.W * cr >= (1L << 30) || (long)d.N * d.OH * d.OW * d.Cout >= (1L << 32)) return false;
     const long tiles = (long)d.N * ((d.OW + 15) / 16) * ((d.OH + 15) / 16);

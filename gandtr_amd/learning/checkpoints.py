@@ -2,7 +2,7 @@
 File format: {"type","frozen","network_params":{"model","runtime"},"model_state"} (mdir/learning/network.py:212-220)."""
 import torch
 
-from ..tools.utils import fs_open
+from .network import load_restricted
 
 
 class Checkpoints:
@@ -10,9 +10,8 @@ class Checkpoints:
     def load_network(cls, directory):
         if directory is None:
             return None
-        with fs_open(str(directory)) as handle:
-            # the payload is dicts / lists / strings / numbers / tensors: the restricted loader reads it (no arbitrary unpickling of a
-            # file that may have come over plain http, hub/model.py BASE_URL)
-            checkpoint = torch.load(handle, map_location="cpu", weights_only=True)
+        # the payload is dicts / lists / strings / numbers / tensors: the restricted loader reads it (no arbitrary unpickling of a
+        # file that may have come over plain http, hub/model.py BASE_URL)
+        checkpoint = load_restricted(directory)
         assert "net" not in checkpoint.get("_networks_included", {})
         return {"net": checkpoint, **checkpoint.pop("_networks_included", {})}

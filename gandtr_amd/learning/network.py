@@ -43,10 +43,23 @@ def _as_model_input(x):
     return x if isinstance(x, ScaledInput) else tensors.as_tensor(x)
 
 
+def load_restricted(path):
+    """torch.load with the restricted unpickler; a checkpoint that carries a type outside torch's allow-list fails with the name of that
+    type and the way to admit it, instead of a bare UnpicklingError from inside hubconf.*(pretrained=True)."""
+    import pickle
+    with fs_open(str(path)) as handle:
+        try:
+            return torch.load(handle, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as exc:
+            raise RuntimeError(
+                f"checkpoint {path} holds an object the restricted loader does not admit ({exc}). If the type named above is benign, "
+                "register it with torch.serialization.add_safe_globals([...]) before loading; unrestricted unpickling of downloaded "
+                "files is deliberately not offered.") from exc
+
+
 def _load_torch(path):
     """checkpoint payloads are dicts / lists / strings / tensors: no arbitrary unpickling"""
-    with fs_open(path) as handle:
-        return torch.load(handle, map_location="cpu", weights_only=True)
+    return load_restricted(path)
 
 
 class Network:

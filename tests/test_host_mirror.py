@@ -374,3 +374,16 @@ def test_whitening_stage_signatures_without_a_device():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             stage.learn_lw_whitening({}, (["a", "b"], np.zeros((2, 4)), ["a"], ["b"]))
+
+
+def test_restricted_checkpoint_loader_names_the_offending_type(tmp_path):
+    """a hub checkpoint carrying a type outside torch's allow-list must fail with a message that says so (and how to admit
+    the type), not with a bare UnpicklingError from inside hubconf; a plain payload loads."""
+    import pathlib
+    from gandtr_amd.learning.network import load_restricted
+    good, bad = tmp_path / "good.pth", tmp_path / "bad.pth"
+    torch.save({"network_params": {"model": {"type": "x"}}, "model_state": {"w": torch.ones(2)}}, good)
+    torch.save({"network_params": {"path": pathlib.PurePosixPath("/a")}}, bad)
+    assert load_restricted(good)["model_state"]["w"].sum() == 2
+    with pytest.raises(RuntimeError, match="add_safe_globals"):
+        load_restricted(bad)
