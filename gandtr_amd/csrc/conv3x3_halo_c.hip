@@ -41,6 +41,12 @@
 #ifndef GDT_C_DEPTH_RES
 #define GDT_C_DEPTH_RES 1
 #endif
+#ifndef GDT_C_DEPTH_SHIFT
+#define GDT_C_DEPTH_SHIFT 2     // ... shift forms (stride-2, transposed): little matrix work per halo byte, the rounds in flight set the HBM rate
+#endif
+#ifndef GDT_C_DEPTH_SHIFT_RES
+#define GDT_C_DEPTH_SHIFT_RES 2
+#endif
 // cache policy of the streamed loads: bit 1 = weight fragments, bit 2 = halo pieces are fetched non-temporal (the line is not kept in the
 // CU's 32 KB L1: with two substeps of weights per wave in flight the outstanding lines alone fill it)
 #ifndef GDT_C_NT
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
     // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
     // (the shift forms have 16 substeps for 10 rounds, one substep apart: they keep DEPTH = 2 rounds in flight instead)
-    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? 2 : ((MODE & 6) ? GDT_C_DEPTH_RES : GDT_C_DEPTH), SPR = SLOTS / (NR + DEPTH);
+    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? (RES ? GDT_C_DEPTH_SHIFT_RES : GDT_C_DEPTH_SHIFT) : ((MODE & 6) ? GDT_C_DEPTH_RES : GDT_C_DEPTH), SPR = SLOTS / (NR + DEPTH);
     static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
