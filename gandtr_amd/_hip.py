@@ -26,6 +26,20 @@ class IngestItem(ctypes.Structure):
                 ("out_w", c_int), ("out_h", c_int), ("dst_hwc", c_void_p), ("dst_chw", c_void_p)]
 
 
+class JpegInfo(ctypes.Structure):
+    """struct gdt_jpeg_info (include/gandtr_hip.h)."""
+    _fields_ = [("width", c_int), ("height", c_int), ("ncomp", c_int), ("hs", c_int * 3), ("vs", c_int * 3), ("tq", c_int * 3),
+                ("td", c_int * 3), ("ta", c_int * 3), ("restart_interval", c_int), ("mcus_x", c_int), ("mcus_y", c_int),
+                ("blocks_per_mcu", c_int), ("nsegments", c_int), ("scan_offset", ctypes.c_ulonglong),
+                ("scan_capacity", ctypes.c_ulonglong), ("quant", (ctypes.c_ushort * 64) * 4), ("huff_bits", (ctypes.c_ubyte * 17) * 4),
+                ("huff_vals", (ctypes.c_ubyte * 256) * 4)]
+
+
+class JpegItem(ctypes.Structure):
+    """struct gdt_jpeg_item (include/gandtr_hip.h)."""
+    _fields_ = [("info", POINTER(JpegInfo)), ("scan", c_void_p), ("seg_off", POINTER(ctypes.c_uint)), ("dst_hwc", c_void_p)]
+
+
 _FP = POINTER(c_float)
 _IP = POINTER(c_int)
 
@@ -68,6 +82,10 @@ SIGNATURES = {
     "gdt_ingest_batch_workspace_bytes": (c_int, [POINTER(IngestItem), c_int, c_int, POINTER(c_size_t)]),
     "gdt_ingest_resize_u8_batch": (c_int, [POINTER(IngestItem), c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_size_t,
                                            c_void_p]),
+    "gdt_jpeg_parse": (c_int, [c_void_p, c_size_t, POINTER(JpegInfo)]),
+    "gdt_jpeg_extract_scan": (c_int, [c_void_p, c_size_t, POINTER(JpegInfo), c_void_p, POINTER(ctypes.c_uint)]),
+    "gdt_jpeg_decode_workspace_bytes": (c_int, [POINTER(JpegItem), c_int, POINTER(c_size_t)]),
+    "gdt_jpeg_decode_u8_batch": (c_int, [POINTER(JpegItem), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gdt_whiten_learn_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_whiten_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                  c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,126 @@
+"""JPEG decoding on the device: the first half of the ingest row.
+
+Reference (per image, on the CPU): ``pil_loader`` = ``Image.open(f).convert('RGB')`` (mdir/external/cirtorch/datasets/datahelpers.py:39-47),
+called from ``ImagesFromList.__getitem__`` (genericdataset.py:66-102) before ``imresize`` and the transform.  Here the FILE bytes are
+uploaded and decoded by HIP launches (gandtr_amd/csrc/jpeg.hip): Huffman decoding in parallel within each file, DC prediction,
+dequantisation + inverse DCT, chroma upsampling and colour conversion -- bit-identical to Pillow / libjpeg-turbo.  The host parses the
+headers and strips the byte stuffing from the entropy-coded segment while staging it for the upload; it decodes nothing.
+
+Baseline files only (8-bit, Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0).  ``parse`` raises ValueError for
+anything else, with the reason; ``load_many`` passes that on unless the caller supplies its own loader for such files."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+class Parsed:
+    """Headers of one baseline JPEG file (``info`` = struct gdt_jpeg_info) plus the file bytes."""
+
+    def __init__(self, data):
+        if not isinstance(data, (bytes, bytearray, memoryview)):
+            raise TypeError("JPEG data must be bytes-like")
+        self.data = bytes(data)
+        self.info = _hip.JpegInfo()
+        _hip.check(_hip.load().gdt_jpeg_parse(self.data, len(self.data), ctypes.byref(self.info)))
+
+    @property
+    def size(self):
+        return self.info.width, self.info.height
+
+    @property
+    def mode(self):
+        return "L" if self.info.ncomp == 1 else "RGB"
+
+
+def parse(data):
+    return Parsed(data)
+
+
+def decode_many(blobs, device=None, sequential=False):
+    """Decodes a list of baseline JPEG files (bytes, or ``Parsed``) in one library call.  Returns uint8 H x W x 3 tensors on the device,
+    equal to ``np.asarray(Image.open(f).convert('RGB'))``.  ``sequential`` selects the one-thread-per-restart-interval entropy decoder
+    (the checker of the parallel one)."""
+    lib = _hip.load()
+    if not blobs:
+        return []
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.type != "cuda":
+        raise ValueError("JPEG decoding runs on a HIP device only (there is no CPU path)")
+    parsed = [b if isinstance(b, Parsed) else Parsed(b) for b in blobs]
+    # staging: every image's un-stuffed scan at a 16-byte aligned offset of ONE pinned buffer -> one upload
+    offs, total = [], 0
+    for p in parsed:
+        offs.append(total)
+        total += (int(p.info.scan_capacity) + 15) // 16 * 16
+    stage = torch.empty(total, dtype=torch.uint8).pin_memory()
+    base = stage.data_ptr()
+    seg_tables = []
+    for p, off in zip(parsed, offs):
+        seg = (ctypes.c_uint * (p.info.nsegments + 1))()
+        _hip.check(lib.gdt_jpeg_extract_scan(p.data, len(p.data), ctypes.byref(p.info), ctypes.c_void_p(base + off), seg))
+        seg_tables.append(seg)
+    with torch.cuda.device(device):
+        scans = stage.to(device, non_blocking=True)
+        out_offs, out_total = [], 0
+        for p in parsed:
+            out_offs.append(out_total)
+            out_total += (p.info.width * p.info.height * 3 + 255) // 256 * 256
+        out = torch.empty(out_total, dtype=torch.uint8, device=device)
+        items = (_hip.JpegItem * len(parsed))()
+        for i, (p, off, oo) in enumerate(zip(parsed, offs, out_offs)):
+            items[i].info = ctypes.pointer(p.info)
+            items[i].scan = scans.data_ptr() + off
+            items[i].seg_off = ctypes.cast(seg_tables[i], ctypes.POINTER(ctypes.c_uint))
+            items[i].dst_hwc = out.data_ptr() + oo
+        nbytes = ctypes.c_size_t()
+        _hip.check(lib.gdt_jpeg_decode_workspace_bytes(items, len(parsed), ctypes.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        _hip.check(lib.gdt_jpeg_decode_u8_batch(items, len(parsed), 1 if sequential else 0, ws.data_ptr(), nbytes.value,
+                                                torch.cuda.current_stream().cuda_stream))
+    return [out[oo:oo + p.info.width * p.info.height * 3].view(p.info.height, p.info.width, 3) for p, oo in zip(parsed, out_offs)]
+
+
+def decode(blob, device=None):
+    return decode_many([blob], device)[0]
+
+
+def _read(source):
+    if isinstance(source, (bytes, bytearray, memoryview)):
+        return bytes(source)
+    with open(source, "rb") as handle:
+        return handle.read()
+
+
+def load_many(sources, device=None, host_loader=None):
+    """Device-side ``pil_loader`` over a list of paths / file contents: decoded uint8 H x W x 3 tensors on the device, in input order.
+    Baseline JPEG files go through ``decode_many`` (one call for all of them).  A file the device decoder does not take (PNG,
+    progressive JPEG, ...) raises the ValueError of ``parse`` -- unless the caller passes ``host_loader``, a callable
+    ``bytes -> H x W x 3 uint8 array`` (the reference's own ``pil_loader`` is the natural one); its result is uploaded as is.
+    Nothing in this module decodes on the host by itself."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    blobs = [_read(s) for s in sources]
+    parsed, on_device, rest = [], [], []
+    for i, b in enumerate(blobs):
+        try:
+            parsed.append(Parsed(b))
+            on_device.append(i)
+        except ValueError:
+            if host_loader is None:
+                raise
+            rest.append(i)
+    out = [None] * len(blobs)
+    for i, t in zip(on_device, decode_many(parsed, device)):
+        out[i] = t
+    for i in rest:
+        out[i] = torch.from_numpy(np.ascontiguousarray(host_loader(blobs[i]), dtype=np.uint8)).to(device)
+    return out
+
+
+def ingest_files(sources, imsize, mean, std, clahe_clip=None, clahe_grid=8, device=None, host_loader=None):
+    """``ImagesFromList.__getitem__`` (genericdataset.py:66-102) for a list of files, on the device end to end: decode, ``imresize`` to
+    ``imsize`` (Pillow's thumbnail arithmetic), [0, 1] scaling, optional CLAHE, normalisation.  Returns fp32 3 x h x w tensors."""
+    from . import ingest
+    return ingest.ingest_many(load_many(sources, device, host_loader), imsize, mean, std, clahe_clip, clahe_grid)

@@ -222,6 +222,49 @@ int gdt_ingest_resize_u8_batch(const gdt_ingest_item* items, int n, int c, const
                                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * JPEG decoding on the device (the first half of the ingest row)
+ * Replaces  pil_loader: Image.open(f).convert('RGB')  (mdir/external/cirtorch/datasets/datahelpers.py:39-47, called per image from
+ * genericdataset.py:66-102) for baseline JPEG files: 8-bit, Huffman-coded, one interleaved scan, grayscale or YCbCr with 4:4:4 / 4:2:2 /
+ * 4:2:0 sampling, with or without restart markers.  The output is bit-identical to Pillow's (libjpeg-turbo defaults: the integer
+ * "islow" inverse DCT, "fancy" triangle chroma upsampling, the fixed-point YCbCr -> RGB tables).  Anything else (progressive,
+ * arithmetic-coded, 12-bit, CMYK / RGB-coded files, other sampling factors) is reported as GDT_ERR_INVALID by gdt_jpeg_parse so that the
+ * caller can hand that file to its general-purpose loader; nothing is decoded on the host here.
+ *
+ * Host side (pure C, no device): gdt_jpeg_parse reads the headers of one file into a gdt_jpeg_info (geometry, tables, where the
+ * entropy-coded segment lies, how many restart intervals it has); gdt_jpeg_extract_scan copies that segment with the 0xFF00 byte
+ * stuffing and the restart markers removed into `dst` (capacity info.scan_capacity; to be uploaded) and writes the info.nsegments + 1
+ * byte offsets of the restart intervals within it.
+ * Device side: gdt_jpeg_decode_u8_batch decodes a list of such images in a fixed number of launches for the whole list.  Huffman
+ * decoding is parallel WITHIN a file: every 128-byte piece of an interval is decoded by its own thread from a guessed state, the
+ * guesses are repaired by re-decoding from the neighbour's exit state until nothing changes (Huffman streams self-synchronise within a
+ * few symbols; the call reads one flag per round of four launches, so it synchronises the stream), then the coefficients are written,
+ * the DC predictions are prefix-summed per interval and component, and dequantisation + inverse DCT, upsampling and colour conversion
+ * run per block / per pixel.  mode = 1 decodes every interval with ONE thread instead (the checker of the parallel decoder).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct gdt_jpeg_info {
+    int width, height, ncomp;                 /* ncomp 1 (grayscale) or 3 (YCbCr) */
+    int hs[3], vs[3], tq[3], td[3], ta[3];     /* per component: sampling factors, quantisation / DC / AC table numbers */
+    int restart_interval;                      /* in MCUs, 0 = none */
+    int mcus_x, mcus_y, blocks_per_mcu;
+    int nsegments;                             /* restart intervals in the scan (1 without restart markers) */
+    unsigned long long scan_offset;            /* first entropy-coded byte in the file */
+    unsigned long long scan_capacity;          /* bytes gdt_jpeg_extract_scan may write (>= the unstuffed size + padding) */
+    unsigned short quant[4][64];               /* natural (row-major) order */
+    unsigned char huff_bits[4][17];            /* tables 0-1: DC 0 / 1, 2-3: AC 0 / 1; bits[l] = number of codes of length l */
+    unsigned char huff_vals[4][256];
+} gdt_jpeg_info;
+int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info);
+int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off);
+typedef struct gdt_jpeg_item {
+    const gdt_jpeg_info* info;     /* host */
+    const unsigned char* scan;     /* device: the bytes gdt_jpeg_extract_scan produced (scan_capacity of them) */
+    const unsigned int* seg_off;   /* host: info->nsegments + 1 offsets into scan */
+    unsigned char* dst_hwc;        /* device: [height][width][3] uint8 RGB (grayscale replicated, as convert('RGB') does) */
+} gdt_jpeg_item;
+int gdt_jpeg_decode_workspace_bytes(const gdt_jpeg_item* items, int n, size_t* bytes);
+int gdt_jpeg_decode_u8_batch(const gdt_jpeg_item* items, int n, int mode, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Learned whitening ("next" row of SURVEY.md section 8f, rank 4): the {m, P} that gdt_whiten applies
  * Replaces  whitenlearn(X, qidxs, pidxs)  (mdir/external/cirtorch/utils/whiten.py:37-70; called with float64 D x N values from
  * mdir/stages/whiten.py:30-75).  x: [n_vec][d] fp32 descriptor rows (device), qidx / pidx: int32 [n_pairs] (device) row numbers of

@@ -1,0 +1,137 @@
+"""Device JPEG decoder (gandtr_amd/csrc/jpeg.hip through the C ABI) against the reference's loader, pil_loader =
+Image.open(f).convert('RGB') (mdir/external/cirtorch/datasets/datahelpers.py:39-47): byte-exact, every sampling mode Pillow writes,
+odd sizes, custom Huffman tables, restart intervals, both entropy decoders (parallel pieces / one thread per interval)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from gandtr_amd import jpeg
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+
+
+def _picture(w, h, seed, gray=False):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    planes = []
+    for c in range(1 if gray else 3):
+        base = 128 + 90 * np.sin(xx / (5.0 + 3 * c) + seed) * np.cos(yy / (7.0 + c)) + 30 * np.sin((xx + yy) / 23.0)
+        noise = rng.normal(0, 25, (h, w)) * (rng.rand(h, w) < 0.4)
+        edges = 80.0 * (((xx // 13 + yy // 11) % 2) > 0)
+        planes.append(np.clip(base + noise + edges - 40, 0, 255))
+    arr = np.stack(planes, -1).astype(np.uint8)
+    return Image.fromarray(arr[:, :, 0], "L") if gray else Image.fromarray(arr, "RGB")
+
+
+def _encode(img, **kw):
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _reference(blob):
+    with Image.open(io.BytesIO(blob)) as img:
+        return np.asarray(img.convert("RGB")).copy()
+
+
+def _check(blobs, sequential=False):
+    got = jpeg.decode_many(blobs, "cuda:0", sequential=sequential)
+    torch.cuda.synchronize()
+    for k, (g, blob) in enumerate(zip(got, blobs)):
+        want = _reference(blob)
+        g = g.cpu().numpy()
+        assert g.shape == want.shape, (k, g.shape, want.shape)
+        bad = np.argwhere(g != want)
+        assert bad.size == 0, "image %d (%dx%d): %d differing samples, first at %s: %s vs %s" % (
+            k, want.shape[1], want.shape[0], len(bad), bad[0], g[tuple(bad[0])], want[tuple(bad[0])])
+
+
+SIZES = [(1, 1), (2, 3), (7, 5), (8, 8), (16, 16), (17, 33), (5, 64), (64, 48), (131, 257), (320, 213)]
+
+
+@pytest.mark.parametrize("sequential", [True, False], ids=["one-thread-per-interval", "parallel-pieces"])
+@pytest.mark.parametrize("subsampling", [0, 1, 2], ids=["444", "422", "420"])
+def test_colour_files_match_pillow(subsampling, sequential):
+    blobs = [_encode(_picture(w, h, 3 * i + subsampling), quality=q, subsampling=subsampling)
+             for i, (w, h) in enumerate(SIZES) for q in (35, 90)]
+    _check(blobs, sequential)
+
+
+@pytest.mark.parametrize("sequential", [True, False], ids=["one-thread-per-interval", "parallel-pieces"])
+def test_grayscale_optimised_tables_and_extreme_qualities(sequential):
+    blobs = [_encode(_picture(w, h, 7 + i, gray=True), quality=80) for i, (w, h) in enumerate(SIZES)]
+    blobs += [_encode(_picture(97, 61, 5), quality=q, subsampling=s, optimize=True) for q in (5, 50, 100) for s in (0, 2)]
+    blobs += [_encode(_picture(40, 40, 9), quality=100, subsampling=0), _encode(_picture(333, 100, 11), quality=1, subsampling=2)]
+    _check(blobs, sequential)
+
+
+@pytest.mark.parametrize("sequential", [True, False], ids=["one-thread-per-interval", "parallel-pieces"])
+def test_restart_intervals(sequential):
+    blobs = []
+    for i, (kw, sub) in enumerate([({"restart_marker_blocks": 1}, 2), ({"restart_marker_blocks": 7}, 0), ({"restart_marker_rows": 1}, 2),
+                                   ({"restart_marker_rows": 2}, 1), ({"restart_marker_blocks": 1000000}, 2)]):
+        blobs.append(_encode(_picture(150 + 9 * i, 90 + 5 * i, 20 + i), quality=85, subsampling=sub, **kw))
+    blobs.append(_encode(_picture(64, 64, 31, gray=True), quality=70, restart_marker_blocks=3))
+    infos = [jpeg.parse(b).info for b in blobs]
+    assert infos[0].nsegments > 1 and infos[2].nsegments > 1 and infos[4].nsegments == 1
+    _check(blobs, sequential)
+
+
+def test_large_noisy_image_many_pieces_converges():
+    """a scan of about a megabyte = thousands of 128-byte pieces per file; high-entropy content gives the self-synchronisation
+    the least help (few zero runs / end-of-block symbols)"""
+    rng = np.random.RandomState(0)
+    noisy = Image.fromarray(rng.randint(0, 256, (900, 1400, 3), dtype=np.uint8), "RGB")
+    photo = _picture(1600, 1200, 2)
+    blobs = [_encode(noisy, quality=95, subsampling=0), _encode(photo, quality=92, subsampling=2), _encode(noisy, quality=60, subsampling=2)]
+    assert len(blobs[0]) > 1000000
+    _check(blobs, False)
+
+
+def test_batch_of_mixed_files_equals_one_by_one():
+    blobs = [_encode(_picture(200 + 17 * i, 100 + 31 * i, i), quality=70 + 3 * i, subsampling=i % 3) for i in range(7)]
+    blobs.insert(3, _encode(_picture(77, 191, 99, gray=True), quality=88))
+    together = jpeg.decode_many(blobs, "cuda:0")
+    for t, b in zip(together, blobs):
+        assert torch.equal(t, jpeg.decode(b, "cuda:0"))
+    _check(blobs)
+
+
+def test_unsupported_files_raise_and_host_loader_is_explicit():
+    progressive = _encode(_picture(64, 64, 1), quality=80, progressive=True)
+    cmyk = _encode(_picture(32, 32, 2).convert("CMYK"), quality=80)
+    png = io.BytesIO()
+    _picture(20, 20, 3).save(png, "PNG")
+    for blob, word in ((progressive, "progressive"), (cmyk, "three-component"), (png.getvalue(), "SOI")):
+        with pytest.raises(ValueError, match=word):
+            jpeg.parse(blob)
+    good = _encode(_picture(48, 40, 4), quality=90)
+    with pytest.raises(ValueError):
+        jpeg.load_many([good, progressive], "cuda:0")
+    calls = []
+
+    def loader(data):
+        calls.append(len(data))
+        return _reference(data)
+
+    out = jpeg.load_many([good, progressive], "cuda:0", host_loader=loader)
+    assert calls == [len(progressive)]
+    assert np.array_equal(out[0].cpu().numpy(), _reference(good)) and np.array_equal(out[1].cpu().numpy(), _reference(progressive))
+
+
+def test_files_to_network_input_matches_the_pillow_pipeline():
+    """decode + imresize + totensor + normalize on the device == the reference's loader + transform on the host
+    (genericdataset.py:66-102): the decoded pixels are identical, so the existing ingest parity carries over; checked end to end here"""
+    from gandtr_amd import ingest
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    blobs = [_encode(_picture(500, 375, 1), quality=90, subsampling=2), _encode(_picture(300, 420, 2), quality=85, subsampling=0)]
+    got = jpeg.ingest_files(blobs, 256, mean, std, device="cuda:0")
+    for g, b in zip(got, blobs):
+        with Image.open(io.BytesIO(b)) as img:
+            img = img.convert("RGB")
+            img.thumbnail((256, 256), Image.LANCZOS)
+            want = (np.asarray(img).astype(np.float32) / 255.0 - np.array(mean, np.float32)) / np.array(std, np.float32)
+        assert np.abs(g.cpu().numpy() - want.transpose(2, 0, 1)).max() < 1e-5

@@ -1,0 +1,83 @@
+"""Host half of the device JPEG decoder (header parsing, un-stuffing, restart intervals): pure C, no device needed."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+from gandtr_amd import _hip, jpeg
+
+Image = pytest.importorskip("PIL.Image")
+
+
+def _encode(arr, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _scan(p):
+    out = (ctypes.c_ubyte * int(p.info.scan_capacity))()
+    seg = (ctypes.c_uint * (p.info.nsegments + 1))()
+    _hip.check(_hip.load().gdt_jpeg_extract_scan(p.data, len(p.data), ctypes.byref(p.info), out, seg))
+    return bytes(out), list(seg)
+
+
+def test_headers_agree_with_pillow():
+    rng = np.random.RandomState(0)
+    for (h, w), sub, q in [((33, 47), 2, 90), ((8, 8), 0, 50), ((100, 3), 1, 75), ((64, 64), 2, 20)]:
+        blob = _encode(rng.randint(0, 256, (h, w, 3), dtype=np.uint8), quality=q, subsampling=sub)
+        p = jpeg.parse(blob)
+        with Image.open(io.BytesIO(blob)) as img:
+            assert p.size == img.size and p.mode == img.mode
+            assert (p.info.hs[0], p.info.vs[0]) == {0: (1, 1), 1: (2, 1), 2: (2, 2)}[sub]
+            # quantisation tables: Pillow reports them in zigzag order of the file; info holds the natural order
+            zig = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49,
+                   56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+            for tq, table in img.quantization.items():
+                # (Pillow >= 8.3 de-zigzags: accept either convention, exactly)
+                nat = list(p.info.quant[tq])
+                assert list(table) == nat or [nat[zig[i]] for i in range(64)] == list(table)
+        assert p.info.mcus_x == -(-w // (8 * p.info.hs[0])) and p.info.mcus_y == -(-h // (8 * p.info.vs[0]))
+        assert p.info.nsegments == 1 and p.info.restart_interval == 0
+    gray = jpeg.parse(_encode(rng.randint(0, 256, (20, 30), dtype=np.uint8), quality=70))
+    assert gray.mode == "L" and gray.info.blocks_per_mcu == 1 and gray.info.mcus_x == 4 and gray.info.mcus_y == 3
+
+
+def test_scan_extraction_removes_stuffing_and_cuts_at_restart_markers():
+    rng = np.random.RandomState(1)
+    arr = rng.randint(0, 256, (96, 160, 3), dtype=np.uint8)             # noise at quality 100: plenty of 0xFF bytes in the scan
+    plain = jpeg.parse(_encode(arr, quality=100, subsampling=0))
+    raw = plain.data[int(plain.info.scan_offset):]
+    stuffed = raw.count(b"\xff\x00")
+    assert stuffed > 10
+    data, seg = _scan(plain)
+    assert seg[0] == 0 and seg[1] == len(raw) - 2 - stuffed                 # (minus the EOI marker and the stuffing zeros)
+    assert data[:seg[1]] == raw[:-2].replace(b"\xff\x00", b"\xff") and set(data[seg[1]:]) == {0}
+    rst = jpeg.parse(_encode(arr, quality=90, subsampling=2, restart_marker_rows=1))
+    assert rst.info.restart_interval == rst.info.mcus_x and rst.info.nsegments == rst.info.mcus_y
+    data, seg = _scan(rst)
+    assert len(seg) == rst.info.nsegments + 1 and all(a < b for a, b in zip(seg, seg[1:]))
+    # the same picture without restart markers carries the same coefficients: equal size up to the padding bits of each interval
+    one = jpeg.parse(_encode(arr, quality=90, subsampling=2))
+    assert abs(_scan(one)[1][1] - seg[-1]) <= rst.info.nsegments
+
+
+def test_unsupported_kinds_are_refused_with_the_reason():
+    rng = np.random.RandomState(2)
+    arr = rng.randint(0, 256, (40, 40, 3), dtype=np.uint8)
+    with pytest.raises(ValueError, match="progressive"):
+        jpeg.parse(_encode(arr, quality=80, progressive=True))
+    buf = io.BytesIO()
+    Image.fromarray(arr).convert("CMYK").save(buf, "JPEG")
+    with pytest.raises(ValueError, match="three-component"):
+        jpeg.parse(buf.getvalue())
+    with pytest.raises(ValueError, match="SOI"):
+        jpeg.parse(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    good = _encode(arr, quality=80)
+    with pytest.raises(ValueError):
+        jpeg.parse(good[:200])                                            # truncated inside the headers
+    with pytest.raises(TypeError):
+        jpeg.parse("not bytes")
+    with pytest.raises(ValueError, match="HIP device"):
+        jpeg.decode_many([good], "cpu")
