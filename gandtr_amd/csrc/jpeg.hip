@@ -24,6 +24,8 @@
 // (it has to find the end of the scan anyway).  Everything is sized per call in the caller's workspace; a whole list of images is
 // decoded by the same launches (blockIdx.y or a binary search over the descriptor tables selects the image).
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -339,15 +341,20 @@ struct Reader {
 int fail(const std::string& msg) { gdt_set_error("jpeg: " + msg); return GDT_ERR_INVALID; }
 
 // walks the entropy-coded bytes from `pos`: counts the bytes that remain after un-stuffing, the restart markers, and finds the marker that ends the scan
-struct ScanWalk { size_t data_bytes = 0; int restarts = 0; int end_marker = -1; size_t end_pos = 0; };
-ScanWalk walk_scan(const unsigned char* f, size_t n, size_t pos, unsigned char* dst, unsigned int* seg_off) {
+struct ScanWalk { size_t data_bytes = 0; int restarts = 0; int end_marker = -1; size_t end_pos = 0; bool overflow = false; };
+// (dst == nullptr: measure only; otherwise at most `cap` bytes and `max_restarts` interval offsets are written -- a file that does not
+// match the info it is extracted with must not overrun the caller's buffers)
+ScanWalk walk_scan(const unsigned char* f, size_t n, size_t pos, unsigned char* dst, size_t cap, unsigned int* seg_off, int max_restarts) {
     ScanWalk w;
     size_t o = 0;
     if (seg_off) seg_off[0] = 0;
     while (pos < n) {
         const unsigned char* hit = (const unsigned char*)memchr(f + pos, 0xFF, n - pos);
         const size_t stop = hit ? (size_t)(hit - f) : n;
-        if (dst) memcpy(dst + o, f + pos, stop - pos);
+        if (dst) {
+            if (o + (stop - pos) + 1 > cap) { w.overflow = true; break; }
+            memcpy(dst + o, f + pos, stop - pos);
+        }
         o += stop - pos;
         pos = stop;
         if (pos >= n) break;
@@ -356,13 +363,17 @@ ScanWalk walk_scan(const unsigned char* f, size_t n, size_t pos, unsigned char* 
         if (q >= n) { pos = n; break; }
         const int m = f[q];
         if (m == 0x00) { if (dst) dst[o] = 0xFF; ++o; pos = q + 1; continue; }
-        if (m >= 0xD0 && m <= 0xD7) { ++w.restarts; if (seg_off) seg_off[w.restarts] = (unsigned int)o; pos = q + 1; continue; }
+        if (m >= 0xD0 && m <= 0xD7) {
+            ++w.restarts;
+            if (seg_off) { if (w.restarts > max_restarts) { w.overflow = true; break; } seg_off[w.restarts] = (unsigned int)o; }
+            pos = q + 1;
+            continue;
+        }
         w.end_marker = m; w.end_pos = q + 1;
         break;
     }
     if (w.end_marker < 0) w.end_pos = n;
     w.data_bytes = o;
-    if (seg_off) seg_off[w.restarts + 1] = (unsigned int)o;
     return w;
 }
 
@@ -471,7 +482,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
     info->blocks_per_mcu = info->ncomp == 1 ? 1 : hmax * vmax + 2;
     if ((long long)info->mcus_x * info->mcus_y * info->blocks_per_mcu >= (1LL << 26)) return fail("image too large");
     info->scan_offset = r.pos;
-    const ScanWalk w = walk_scan(f, n, r.pos, nullptr, nullptr);
+    const ScanWalk w = walk_scan(f, n, r.pos, nullptr, 0, nullptr, 0);
     if (w.end_marker >= 0 && w.end_marker != 0xD9) return fail("more than one scan (or a marker inside the scan) -- not decoded on the device");
     if (w.data_bytes >= (1u << 28)) return fail("scan too large");
     const long long total_mcus = (long long)info->mcus_x * info->mcus_y;
@@ -616,6 +627,8 @@ int run_decode(const gdt_jpeg_item* items, int n, int mode, const Plan& p, char*
             converged = flags[group - 1] == 0;
         }
         if (!converged) { gdt_set_error("jpeg: the parallel entropy decoder did not reach a fixed point"); return GDT_ERR_NOT_CONVERGED; }
+        static const bool trace = getenv("GDT_JPEG_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[jpeg] %d files, %u intervals, %u pieces (longest interval %u): fixed point after %u repair rounds\n", n, nseg, p.nsub, longest, round);
         hipLaunchKernelGGL(jpeg_scan_kernel, dim3(nseg), dim3(256), 0, stream, d_segs, d_nblk, d_blk0);
     } else {
         GDT_CHECK_HIP(hipMemsetAsync(d_blk0, 0, (size_t)p.nsub * 4, stream));
@@ -640,11 +653,10 @@ int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info
 int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off) {
     GDT_REQUIRE(file != nullptr && info != nullptr && dst != nullptr && seg_off != nullptr, "jpeg: null argument");
     GDT_REQUIRE(info->scan_offset > 0 && info->scan_offset <= nbytes && info->nsegments >= 1, "jpeg: info was not filled by gdt_jpeg_parse");
-    // (the walk is bounded by what the parse pass measured on the same bytes; a different file is caught below)
-    const ScanWalk probe = walk_scan(file, nbytes, info->scan_offset, nullptr, nullptr);
-    GDT_REQUIRE(probe.restarts + 1 == info->nsegments && scan_capacity_for(probe.data_bytes) == info->scan_capacity,
+    const ScanWalk w = walk_scan(file, nbytes, info->scan_offset, dst, info->scan_capacity - 16, seg_off, info->nsegments - 1);
+    GDT_REQUIRE(!w.overflow && w.restarts + 1 == info->nsegments && scan_capacity_for(w.data_bytes) == info->scan_capacity,
                 "jpeg: the file does not match the info");
-    const ScanWalk w = walk_scan(file, nbytes, info->scan_offset, dst, seg_off);
+    seg_off[info->nsegments] = (unsigned int)w.data_bytes;
     memset(dst + w.data_bytes, 0, info->scan_capacity - w.data_bytes);
     return GDT_OK;
 }

@@ -39,6 +39,17 @@ def parse(data):
     return Parsed(data)
 
 
+_stage = None
+
+
+def _staging(nbytes):
+    """pinned upload buffer, grown geometrically and kept (allocating pinned memory costs more than decoding a small file)"""
+    global _stage
+    if _stage is None or _stage.numel() < nbytes:
+        _stage = torch.empty(max(nbytes, 1 << 20) * 3 // 2, dtype=torch.uint8).pin_memory()
+    return _stage[:nbytes]
+
+
 def decode_many(blobs, device=None, sequential=False):
     """Decodes a list of baseline JPEG files (bytes, or ``Parsed``) in one library call.  Returns uint8 H x W x 3 tensors on the device,
     equal to ``np.asarray(Image.open(f).convert('RGB'))``.  ``sequential`` selects the one-thread-per-restart-interval entropy decoder
@@ -55,7 +66,8 @@ def decode_many(blobs, device=None, sequential=False):
     for p in parsed:
         offs.append(total)
         total += (int(p.info.scan_capacity) + 15) // 16 * 16
-    stage = torch.empty(total, dtype=torch.uint8).pin_memory()
+    torch.cuda.current_stream(device).synchronize()      # (an upload from the staging buffer may still be in flight)
+    stage = _staging(total)
     base = stage.data_ptr()
     seg_tables = []
     for p, off in zip(parsed, offs):

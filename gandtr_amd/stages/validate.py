@@ -63,6 +63,27 @@ def extract_vectors(net, images, device=None, batched=None, max_batch=32):
     return torch.stack(cols, dim=1)
 
 
+def extract_vectors_from_files(net, files, image_size, mean_std, device=None, host_loader=None, clahe_clip=None, max_batch=32, chunk=64):
+    """``extract_vectors(net, images, image_size, transform)`` as the reference calls it -- on image FILES (imageretrievalnet.py:312-339
+    builds ``ImagesFromList(root='', images=images, imsize=image_size, transform=transform)`` and a batch-1 loader over it).  ``files``:
+    paths or file contents.  Per chunk of ``chunk`` files: JPEG decoding, ``imresize`` and ``totensor | normalize`` (``mean_std``; with
+    ``clahe_clip`` the hub's ``apply_clahe`` step in between) run on the device (gandtr_amd/jpeg.py, ingest.py -- bit-identical pixels to
+    Pillow's), then ``extract_vectors`` batches the equal-sized ones.  Files the device decoder does not take go to ``host_loader``
+    (bytes -> H x W x 3 uint8; the reference's pil_loader) or raise.  Returns D x N on ``device``."""
+    from .. import jpeg
+    device = torch.device(device) if device is not None else getattr(net, "device", None)
+    if device is None or torch.device(device).type != "cuda":
+        raise ValueError("extract_vectors_from_files decodes on a HIP device; pass decoded tensors to extract_vectors on the CPU")
+    mean, std = mean_std
+    cols = []
+    for lo in range(0, len(files), chunk):
+        tensors = jpeg.ingest_files(files[lo:lo + chunk], image_size, mean, std, clahe_clip=clahe_clip, device=device, host_loader=host_loader)
+        cols.append(extract_vectors(net, tensors, device, batched=True, max_batch=max_batch))
+    if not cols:
+        return extract_vectors(net, [], device)
+    return torch.cat(cols, dim=1)
+
+
 def rank(vecs, qvecs):
     """(scores Ndb x Nq float32, ranks Ndb x Nq int) as numpy arrays: cirscore.py:71-73."""
     if vecs.is_cuda:

@@ -1,0 +1,61 @@
+"""Golden vectors for the device JPEG decoder: small baseline files written by Pillow and what the reference's loader makes of them,
+``np.asarray(Image.open(f).convert('RGB'))`` (pil_loader, mdir/external/cirtorch/datasets/datahelpers.py:39-47).  The decoder the
+reference calls IS Pillow (libjpeg-turbo), so these vectors are outputs of the reference's own code path; the tests check the device
+decoder against them and, where Pillow is installed, that Pillow still reproduces them (i.e. that the fixture pins the library build).
+
+usage:  python tests/golden/make_jpeg_golden.py            (writes jpeg_cases.npz next to this file)
+"""
+import io
+import os
+
+import numpy as np
+import PIL
+from PIL import Image, features
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def picture(w, h, seed, gray=False):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    planes = []
+    for c in range(1 if gray else 3):
+        base = 128 + 90 * np.sin(xx / (5.0 + 3 * c) + seed) * np.cos(yy / (7.0 + c)) + 30 * np.sin((xx + yy) / 23.0)
+        noise = rng.normal(0, 25, (h, w)) * (rng.rand(h, w) < 0.4)
+        planes.append(np.clip(base + noise + 60.0 * (((xx // 13 + yy // 11) % 2) > 0) - 30, 0, 255))
+    arr = np.stack(planes, -1).astype(np.uint8)
+    return Image.fromarray(arr[:, :, 0], "L") if gray else Image.fromarray(arr, "RGB")
+
+
+CASES = [  # name, (w, h), gray, save options
+    ("c444_q90", (45, 37), False, dict(quality=90, subsampling=0)),
+    ("c422_q75", (51, 30), False, dict(quality=75, subsampling=1)),
+    ("c420_q85", (64, 48), False, dict(quality=85, subsampling=2)),
+    ("c420_q30_odd", (33, 17), False, dict(quality=30, subsampling=2)),
+    ("c420_tiny", (3, 2), False, dict(quality=80, subsampling=2)),
+    ("c422_narrow", (4, 40), False, dict(quality=80, subsampling=1)),
+    ("gray_q70", (40, 29), True, dict(quality=70)),
+    ("c420_optimised", (57, 43), False, dict(quality=60, subsampling=2, optimize=True)),
+    ("c444_q100", (24, 24), False, dict(quality=100, subsampling=0)),
+    ("c420_restart_rows", (70, 50), False, dict(quality=85, subsampling=2, restart_marker_rows=1)),
+    ("c444_restart_blocks", (40, 40), False, dict(quality=85, subsampling=0, restart_marker_blocks=3)),
+]
+
+
+def main():
+    out = {"pillow_version": np.array(PIL.__version__), "libjpeg_version": np.array(str(features.version("jpg"))),
+           "libjpeg_turbo": np.array(bool(features.check_feature("libjpeg_turbo"))), "names": np.array([c[0] for c in CASES])}
+    for k, (name, (w, h), gray, opts) in enumerate(CASES):
+        buf = io.BytesIO()
+        picture(w, h, 40 + k, gray).save(buf, "JPEG", **opts)
+        blob = buf.getvalue()
+        with Image.open(io.BytesIO(blob)) as img:
+            rgb = np.asarray(img.convert("RGB")).copy()
+        out["file_" + name] = np.frombuffer(blob, np.uint8)
+        out["rgb_" + name] = rgb
+    np.savez_compressed(os.path.join(HERE, "jpeg_cases.npz"), **out)
+    print("wrote", len(CASES), "cases,", os.path.getsize(os.path.join(HERE, "jpeg_cases.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

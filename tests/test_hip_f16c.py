@@ -364,3 +364,42 @@ def test_config5_full_size_chain(cuda_device):
         got = d[:, i].cpu()
         assert float(torch.nn.functional.cosine_similarity(got, ref, dim=0)) >= 0.9999
         assert float((got - ref).abs().max()) <= 1e-3
+
+
+def test_extract_vectors_from_files_equals_the_pillow_pipeline(cuda_device, tmp_path):
+    """the reference's extract_vectors takes image PATHS (imageretrievalnet.py:312-339: ImagesFromList -> pil_loader -> imresize ->
+    transform, batch 1).  extract_vectors_from_files does decode + resize + normalise on the device; against tensors prepared the
+    reference's way (Pillow decode, thumbnail, numpy normalise) and the same network, every descriptor agrees to 5e-5 -- the decoded
+    and resized pixels are identical (tests/test_hip_jpeg.py, test_hip_ingest.py), what is left is the float normalisation's rounding."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from gandtr_amd.stages.validate import extract_vectors, extract_vectors_from_files
+    import copy
+    import gandtr_amd.learning as L
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False, "path": None,
+           "runtime": {"wrappers": "cirfaketuplebatch", "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [mean, std]}}}
+    cpu_net = L.load_network(copy.deepcopy(emb), "cpu")
+    cpu_net.model.load_state_dict(synth.vgg16_state(0))
+    torch.save(cpu_net.state_dict()["net"], tmp_path / "vgg.pth")
+    net = L.load_network({"path": str(tmp_path / "vgg.pth"), "runtime": copy.deepcopy(emb["runtime"])}, cuda_device).eval()
+    rng = np.random.RandomState(0)
+    blobs, want = [], []
+    for i, (w, h) in enumerate([(300, 200), (200, 300), (300, 200), (260, 260), (200, 300), (300, 200), (90, 120)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([128 + 100 * np.sin(xx / (9.0 + c + i)) * np.cos(yy / (7.0 + i)) + rng.normal(0, 12, (h, w)) for c in range(3)], -1)
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=88, subsampling=(2, 0, 1)[i % 3])
+        blobs.append(buf.getvalue())
+        img = Image.open(io.BytesIO(blobs[-1])).convert("RGB")
+        img.thumbnail((160, 160), Image.LANCZOS)
+        a = (np.asarray(img).astype(np.float32) / 255.0 - np.array(mean, np.float32)) / np.array(std, np.float32)
+        want.append(torch.from_numpy(a.transpose(2, 0, 1).copy()))
+    got = extract_vectors_from_files(net, blobs, 160, (mean, std), cuda_device, chunk=4)
+    ref = extract_vectors(net, want, cuda_device)
+    assert got.shape == ref.shape == (512, 7)
+    assert float((got - ref).abs().max()) < 5e-5 and float(torch.nn.functional.cosine_similarity(got.t(), ref.t(), dim=1).min()) > 0.999999

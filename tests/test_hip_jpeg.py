@@ -135,3 +135,14 @@ def test_files_to_network_input_matches_the_pillow_pipeline():
             img.thumbnail((256, 256), Image.LANCZOS)
             want = (np.asarray(img).astype(np.float32) / 255.0 - np.array(mean, np.float32)) / np.array(std, np.float32)
         assert np.abs(g.cpu().numpy() - want.transpose(2, 0, 1)).max() < 1e-5
+
+
+def test_golden_files():
+    """the committed vectors (tests/golden/jpeg_cases.npz: files + pil_loader's output, make_jpeg_golden.py), both entropy decoders"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_cases.npz"))
+    blobs = [bytes(g["file_" + str(n)]) for n in g["names"]]
+    for sequential in (False, True):
+        got = jpeg.decode_many(blobs, "cuda:0", sequential=sequential)
+        for n, t in zip(g["names"], got):
+            assert np.array_equal(t.cpu().numpy(), g["rgb_" + str(n)]), (str(n), sequential)

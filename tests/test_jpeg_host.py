@@ -81,3 +81,22 @@ def test_unsupported_kinds_are_refused_with_the_reason():
         jpeg.parse("not bytes")
     with pytest.raises(ValueError, match="HIP device"):
         jpeg.decode_many([good], "cpu")
+
+
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_cases.npz"))
+
+
+def test_golden_files_parse_and_pillow_still_reproduces_them():
+    """tests/golden/jpeg_cases.npz (make_jpeg_golden.py): files + the reference loader's output.  Here: every file is accepted by the
+    host parser with the geometry of the stored output, and the installed Pillow decodes it to exactly the stored pixels (so a
+    different libjpeg build would show up here, not as a mystery on the GPU)."""
+    g = _golden()
+    assert bool(g["libjpeg_turbo"])
+    for name in g["names"]:
+        blob, want = bytes(g["file_" + str(name)]), g["rgb_" + str(name)]
+        p = jpeg.parse(blob)
+        assert p.size == (want.shape[1], want.shape[0])
+        with Image.open(io.BytesIO(blob)) as img:
+            assert np.array_equal(np.asarray(img.convert("RGB")), want), name
