@@ -306,6 +306,11 @@ def main():
         r3, _ = rate(lambda: ingest.ingest_many(mixed, 1024, mean, std), 64, steps=20, warmup=3)
         out["next_ingest_1200x1600_to_1024"]["mixed_64_batched_images_per_s"] = r3
         del mixed
+        # "next" row (first half): JPEG files -> decoded pixels on the device (tools/jpeg_bench.py: 64 photo-like
+        # 1024x768 4:2:0 files, quality 90) against the reference's loader (Pillow, one host thread), and files -> normalised 362-pixel tensors
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import jpeg_bench
+        out["next_jpeg_decode_64_files_1024x768"] = jpeg_bench.run()
         # "next" row: learned whitening, D = 2048, 20 k vectors, 8 k pairs (float64)
         from gandtr_amd import whiten_learn
         gq = torch.Generator(device=dev).manual_seed(0)

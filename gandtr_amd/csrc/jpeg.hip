@@ -23,6 +23,7 @@
 // Host work: header parsing, and one pass over the entropy-coded bytes that removes the 0xFF00 stuffing and cuts at restart markers
 // (it has to find the end of the scan anyway).  Everything is sized per call in the caller's workspace; a whole list of images is
 // decoded by the same launches (blockIdx.y or a binary search over the descriptor tables selects the image).
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,28 +73,30 @@ struct DTab {
     unsigned short quant[3][64];                   // per component, natural order
 };
 
-__device__ __forceinline__ unsigned fetch32(const unsigned char* __restrict__ scan, unsigned p) {
-    const unsigned byte = p >> 3, a = byte & ~3u;
-    const unsigned w0 = __builtin_bswap32(*(const unsigned*)(scan + a)), w1 = __builtin_bswap32(*(const unsigned*)(scan + a + 4));
-    const unsigned long long x = ((unsigned long long)w0 << 32) | w1;
-    return (unsigned)((x << (((byte & 3u) << 3) + (p & 7u))) >> 32);
-}
-
 struct HState { unsigned p; int b, z; };
 __device__ __forceinline__ unsigned long long pack_state(const HState& s) { return ((unsigned long long)s.p << 16) | ((unsigned)s.b << 8) | (unsigned)s.z; }
 __device__ __forceinline__ HState unpack_state(unsigned long long v) { HState s; s.p = (unsigned)(v >> 16); s.b = (int)((v >> 8) & 255); s.z = (int)(v & 255); return s; }
 
 // Decodes symbols from state s until the bit position reaches `limit` (a symbol -- code plus its value bits -- is never split).
 // Returns the number of blocks completed.  WRITE: stores the non-zero coefficients of blocks g, g + 1, ... (< g_end) of the image.
-template <bool WRITE>
-__device__ unsigned decode_span(const DImg& im, const DTab& tb, unsigned limit, HState& s, short* __restrict__ coef, unsigned g, unsigned g_end) {
-    const unsigned char* __restrict__ scan = im.scan;
-    unsigned done = 0;
-    const int nY = im.ncomp == 1 ? 1 : im.hs0 * im.vs0;
-    while (s.p < limit) {
-        const unsigned w = fetch32(scan, s.p);
-        const int c = s.b < nY ? 0 : s.b - nY + 1;
-        const int t = s.z == 0 ? im.tdc[c] : 2 + im.tac[c];
+// The bit window lives in a 64-bit register; it is topped up by one aligned dword per symbol at most, fetched one refill AHEAD (its
+// address does not depend on the code lengths), so the only memory access on the symbol-to-symbol critical path is the table look-up
+// (LDS when the whole workgroup works on one file, see the kernels).
+template <bool WRITE, typename Tab>
+__device__ __forceinline__ unsigned decode_span(const DImg& im, const Tab& tb, unsigned limit, HState& s, short* __restrict__ coef, unsigned g, unsigned g_end) {
+    const unsigned* __restrict__ words = (const unsigned*)im.scan;
+    const int nY = im.ncomp == 1 ? 1 : im.hs0 * im.vs0, B = im.B;
+    const unsigned tsel = (unsigned)(im.tdc[0] | (im.tdc[1] << 1) | (im.tdc[2] << 2) | (im.tac[0] << 3) | (im.tac[1] << 4) | (im.tac[2] << 5));
+    unsigned done = 0, p = s.p;
+    int b = s.b, z = s.z;
+    unsigned next = (p >> 5) + 2;
+    unsigned long long buf = (((unsigned long long)__builtin_bswap32(words[next - 2]) << 32) | __builtin_bswap32(words[next - 1])) << (p & 31u);
+    int cnt = 64 - (int)(p & 31u);                   // valid bits at the top of buf (> 32 before every symbol)
+    unsigned pre = words[next];
+    while (p < limit) {
+        const unsigned w = (unsigned)(buf >> 32);
+        const int c = b < nY ? 0 : b - nY + 1;
+        const int t = z == 0 ? (int)((tsel >> c) & 1u) : 2 + (int)((tsel >> (3 + c)) & 1u);
         const unsigned v = w >> 16;
         const unsigned lk = tb.look[t][v >> 7];
         int len, sym;
@@ -110,25 +113,42 @@ __device__ unsigned decode_span(const DImg& im, const DTab& tb, unsigned limit, 
             const int bits = (int)((w << len) >> (32 - ss));
             val = bits < (1 << (ss - 1)) ? bits - (1 << ss) + 1 : bits;
         }
-        if (s.z == 0) {
+        int used = len + ss;
+        if (z == 0) {
             if (WRITE && val) coef[(size_t)g * 64] = (short)val;
-            s.p += len + ss; s.z = 1;
+            z = 1;
         } else if (ss) {
-            s.z += sym >> 4;
-            if (WRITE && s.z < 64) coef[(size_t)g * 64 + d_nat[s.z]] = (short)val;
-            s.z += 1; s.p += len + ss;
+            z += sym >> 4;
+            if (WRITE && z < 64) coef[(size_t)g * 64 + d_nat[z]] = (short)val;
+            z += 1;
         } else {
-            s.p += len;
-            s.z = (sym >> 4) == 15 ? s.z + 16 : 64;
+            used = len;
+            z = (sym >> 4) == 15 ? z + 16 : 64;
         }
-        if (s.z >= 64) {
-            s.z = 0; s.b = s.b + 1 == im.B ? 0 : s.b + 1;
+        p += used; buf <<= used; cnt -= used;
+        if (cnt <= 32) {
+            buf |= (unsigned long long)__builtin_bswap32(pre) << (32 - cnt);
+            cnt += 32;
+            pre = words[++next];
+        }
+        if (z >= 64) {
+            z = 0; b = b + 1 == B ? 0 : b + 1;
             ++done; ++g;
             if (WRITE && g >= g_end) break;
         }
     }
+    s.p = p; s.b = b; s.z = z;
     return done;
 }
+
+// the Huffman tables of the file a workgroup works on, in LDS (the quantisation tables are not needed here)
+struct LdsTab {
+    unsigned short look[4][512];
+    int maxcode[4][18];
+    int valoff[4][18];
+    unsigned char vals[4][256];
+};
+static_assert(sizeof(LdsTab) == offsetof(DTab, quant), "LdsTab is the head of DTab");
 
 __device__ __forceinline__ unsigned seg_of_sub(const DSeg* __restrict__ segs, unsigned nseg, unsigned t) {
     unsigned lo = 0, hi = nseg;                    // last segment with first_sub <= t
@@ -136,11 +156,24 @@ __device__ __forceinline__ unsigned seg_of_sub(const DSeg* __restrict__ segs, un
     return lo;
 }
 
+// which file do the pieces of this workgroup belong to?  (pieces are numbered file by file: first == last => all)
+__device__ __forceinline__ int stage_tables(const DSeg* __restrict__ segs, const DTab* __restrict__ tabs, unsigned nseg, unsigned nsub, LdsTab* sh) {
+    const unsigned t0 = blockIdx.x * 256u, t1 = min(t0 + 255u, nsub - 1u);
+    const unsigned i0 = segs[seg_of_sub(segs, nseg, t0)].img, i1 = segs[seg_of_sub(segs, nseg, t1)].img;
+    if (i0 != i1) return -1;
+    const unsigned* src = (const unsigned*)&tabs[i0];
+    for (unsigned i = threadIdx.x; i < sizeof(LdsTab) / 4; i += 256) ((unsigned*)sh)[i] = src[i];
+    __syncthreads();
+    return (int)i0;
+}
+
 // steps 1 / 2: FIRST = guess pass
 template <bool FIRST>
 __global__ __launch_bounds__(256) void jpeg_sync_kernel(const DImg* __restrict__ imgs, const DSeg* __restrict__ segs, const DTab* __restrict__ tabs,
                                                         unsigned nseg, unsigned nsub, unsigned long long* __restrict__ exit_state,
                                                         unsigned* __restrict__ nblk, unsigned* __restrict__ changed) {
+    __shared__ LdsTab sh;
+    const int staged = stage_tables(segs, tabs, nseg, nsub, &sh);
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= nsub) return;
     const DSeg sg = segs[seg_of_sub(segs, nseg, t)];
@@ -151,7 +184,10 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const DImg* __restrict__
     if (FIRST || k == 0) { s.p = start; s.b = 0; s.z = 0; }
     else s = unpack_state(exit_state[t - 1]);
     unsigned done = 0;
-    if (s.p < limit) done = decode_span<false>(imgs[sg.img], tabs[sg.img], limit, s, nullptr, 0, 0);
+    if (s.p < limit) {
+        if (staged >= 0) done = decode_span<false>(imgs[sg.img], sh, limit, s, nullptr, 0, 0);
+        else done = decode_span<false>(imgs[sg.img], tabs[sg.img], limit, s, nullptr, 0, 0);
+    }
     const unsigned long long e = pack_state(s);
     if (!FIRST && (e != exit_state[t] || done != nblk[t])) *changed = 1u;
     exit_state[t] = e;
@@ -184,6 +220,8 @@ __global__ __launch_bounds__(256) void jpeg_scan_kernel(const DSeg* __restrict__
 __global__ __launch_bounds__(256) void jpeg_write_kernel(const DImg* __restrict__ imgs, const DSeg* __restrict__ segs, const DTab* __restrict__ tabs,
                                                          unsigned nseg, unsigned nsub, const unsigned long long* __restrict__ exit_state,
                                                          const unsigned* __restrict__ blk0, short* __restrict__ coef_base) {
+    __shared__ LdsTab sh;
+    const int staged = stage_tables(segs, tabs, nseg, nsub, &sh);
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= nsub) return;
     const DSeg sg = segs[seg_of_sub(segs, nseg, t)];
@@ -195,7 +233,10 @@ __global__ __launch_bounds__(256) void jpeg_write_kernel(const DImg* __restrict_
     else s = unpack_state(exit_state[t - 1]);
     const DImg& im = imgs[sg.img];
     const unsigned g = sg.first_block + (k == 0 ? 0u : blk0[t]), g_end = sg.first_block + sg.nblocks;
-    if (s.p < limit && g < g_end) decode_span<true>(im, tabs[sg.img], limit, s, coef_base + im.coef_off, g, g_end);
+    if (s.p < limit && g < g_end) {
+        if (staged >= 0) decode_span<true>(im, sh, limit, s, coef_base + im.coef_off, g, g_end);
+        else decode_span<true>(im, tabs[sg.img], limit, s, coef_base + im.coef_off, g, g_end);
+    }
 }
 
 // step 5: DC prediction, one workgroup per (interval, component)
