@@ -36,7 +36,9 @@ struct Pend { f16x8 v[4]; };
 
 // TM = 2: waves 2 x 2, 64 x 64 each (tile 128 x 128); TM = 4: waves 1 x 4, 128 x 64 each (tile 128 x 256) -- a weight fragment
 // then feeds four MFMAs: with two, the weight stream alone asks the full 64 B/clk of the CU's L1 at MFMA rate
-template <bool RES, int DEPTH, int TM>
+// CAT: K-concatenated second operand (ConvLaunch::in2): K-steps [0, Cin / 64) read `in`, the rest read `in2` at the stride-in2_stride pixel of
+// the output pixel (the row -> (n, oy, ox) split is done once per tile of the staging cursor)
+template <bool RES, int DEPTH, int TM, bool CAT = false>
 __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, const int vblocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,13 +65,29 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
     const int lrow = tid >> 3;                                 // 0..31; this thread's rows are lrow + 32 r
     const int q = (lane & 7) ^ ((lrow >> 1) & 7);              // source chunk of its 16-byte piece (XOR swizzle; 32 r keeps it)
     int s_vb = vb, s_tile_m = cur.tile_m, s_step = 0;
-    auto load_pend = [&]() -> Pend {
-        Pend p;
+    const int nk1 = CAT ? d.Cin >> 6 : nk;                     // K-steps of the first operand
+    unsigned row2[CAT ? 4 : 1];                                // element offsets of this thread's four rows in the second operand
+    auto set_rows2 = [&]() {
+        if (!CAT) return;
+        const int hw = d.OH * d.OW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = min(s_tile_m * BM + r * 32 + lrow, d.M - 1);
-            const unsigned off = (unsigned)m * (unsigned)d.Cin + (unsigned)(s_step * 64 + q * 8);
-            p.v[r] = *(const f16x8*)(d.in + off);
+            const int n_ = m / hw, rem = m - n_ * hw, oy = rem / d.OW, ox = rem - oy * d.OW;
+            row2[CAT ? r : 0] = (unsigned)((n_ * d.in2_h + oy * d.in2_stride) * d.in2_w + ox * d.in2_stride) * (unsigned)d.in2_cin;
+        }
+    };
+    set_rows2();
+    auto load_pend = [&]() -> Pend {
+        Pend p;
+        const bool second = CAT && s_step >= nk1;              // (uniform)
+        const f16* base = second ? d.in2 : d.in;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = min(s_tile_m * BM + r * 32 + lrow, d.M - 1);
+            const unsigned off = second ? row2[CAT ? r : 0] + (unsigned)((s_step - nk1) * 64 + q * 8)
+                                        : (unsigned)m * (unsigned)d.Cin + (unsigned)(s_step * 64 + q * 8);
+            p.v[r] = *(const f16x8*)(base + off);
         }
         return p;
     };
@@ -82,7 +100,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
         if (++s_step == nk) {
             s_step = 0;
             const TileAt nx = tile_at(s_vb + gridDim.x);
-            if (nx.valid) { s_tile_m = nx.tile_m; s_vb += gridDim.x; }
+            if (nx.valid) { s_tile_m = nx.tile_m; s_vb += gridDim.x; set_rows2(); }
         }
     };
 
@@ -227,15 +245,15 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
     }
 }
 
-template <bool RES, int DEPTH, int TM>
+template <bool RES, int DEPTH, int TM, bool CAT = false>
 int launch_1x1(const ConvLaunch& d, hipStream_t stream) {
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 0, per_cu = 0;
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_kernel<RES, DEPTH, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        GDT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv1x1_rb_kernel<RES, DEPTH, TM>, NT, LDS_BYTES));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        GDT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, NT, LDS_BYTES));
         static const int cap = [] { const char* e = getenv("GDT_CONV_1X1_WPC"); return e ? atoi(e) : 3; }();
         if (per_cu < 1) per_cu = 1;
         if (per_cu > cap) per_cu = cap;
@@ -243,7 +261,7 @@ int launch_1x1(const ConvLaunch& d, hipStream_t stream) {
     }
     const int vblocks = gdt_grid_for_tiles((d.M + BM - 1) / BM, d.CoutPad / (TM == 4 ? 256 : 128));
     const int grid = vblocks < slots ? vblocks : slots;
-    hipLaunchKernelGGL((conv1x1_rb_kernel<RES, DEPTH, TM>), dim3(grid), dim3(NT), LDS_BYTES, stream, d, vblocks);
+    hipLaunchKernelGGL((conv1x1_rb_kernel<RES, DEPTH, TM, CAT>), dim3(grid), dim3(NT), LDS_BYTES, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -267,6 +285,20 @@ bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d) {
     return (long)((d.M + BM - 1) / BM) * (d.CoutPad / 128) >= min_tiles;
 }
 
+// K-concatenated form: both operands in whole 64-channel K-steps, an even number of them in total, 256-wide tiles, no residual read (the shortcut
+// IS the second operand), 32-bit element offsets into both inputs
+bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_1X1_CAT"); return e ? atoi(e) : 1; }();   // 0 off
+    if (mode == 0 || !d.in2 || !d.w_frag || d.out_f32 || !d.out || d.res) return false;
+    if (d.ntaps != 1 || d.sy != 1 || d.sx != 1 || d.dy0 != 0 || d.dx0 != 0 || d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0) return false;
+    if (d.OHg != d.OH || d.OWg != d.OW || d.OH != d.H || d.OW != d.W) return false;
+    if (d.Cin % 64 != 0 || d.in2_cin % 64 != 0 || d.Kpad != d.Cin + d.in2_cin || (d.Kpad / 64) % 2 != 0 || d.CoutPad % 256 != 0 || d.CoutPad > MAX_COUT || d.Cout % 8 != 0) return false;
+    if (d.in2_stride < 1 || d.in2_stride > 2 || (d.OH - 1) * d.in2_stride >= d.in2_h || (d.OW - 1) * d.in2_stride >= d.in2_w) return false;
+    if (d.stats || d.in_norm || d.in_res || d.in_out || d.phase_cout || d.pool2) return false;
+    if ((long)d.M * d.Cin >= (1L << 32) || (long)d.M * d.Cout >= (1L << 32) || (long)d.N * d.in2_h * d.in2_w * d.in2_cin >= (1L << 32)) return false;
+    return (long)((d.M + BM - 1) / BM) * (d.CoutPad / 128) >= 64;
+}
+
 int gdt_launch_conv_1x1_rb(const ConvLaunch& d_in, hipStream_t stream) {
     // Row order: the reduce convs walk their rows from the END.  Their input is what the expand conv of the previous block has just
     // written front to back, so the rows written last -- the ones still in the 256 MB Infinity Cache -- are read first (and the 3x3
@@ -275,6 +307,7 @@ int gdt_launch_conv_1x1_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int rev = [] { const char* e = getenv("GDT_CONV_1X1_REV"); return e ? atoi(e) : 1; }();
     ConvLaunch d = d_in;
     d.dbg = ((rev & 1) && !d.res) || ((rev & 2) && d.res) ? 2 : 0;
+    if (d.in2) return launch_1x1<false, 2, 4, true>(d, stream);
     const int nk = d.Kpad / 64;
     static const int max_depth = [] { const char* e = getenv("GDT_CONV_1X1_DEPTH"); return e ? atoi(e) : 4; }();
     static const int wide = [] { const char* e = getenv("GDT_CONV_1X1_WIDE"); return e ? atoi(e) : 1; }();

@@ -84,6 +84,10 @@ struct ConvLaunch {
     int stagger_us;               // conv3x3_halo_c.hip: start-up delay step between the four workgroup phase groups (0: none)
     int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
                                   //      written to output pixel (2y + py, 2x + px); Cout / CoutPad count GEMM columns (conv_igemm_rb.hip)
+    // conv1x1_rb.hip, K-concatenated form: a second 1x1 conv (stride in2_stride, its own input tensor in2 [N][in2_h][in2_w][in2_cin]) accumulated into
+    // the same tile -- out = W . in + W2 . in2 with the weights packed as ONE [CoutPad][Cin + in2_cin] matrix (Kpad = Cin + in2_cin): the projection
+    // shortcut of a ResNet Bottleneck folded into its expand conv
+    const f16* in2; int in2_cin, in2_h, in2_w, in2_stride;
 };
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>
@@ -116,6 +120,7 @@ int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* varia
 int gdt_conv_igemm_rb_stats_sets(const ConvLaunch& d);
 bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d);        // conv1x1_rb.hip (streaming 1x1 conv, variant 945128)
 int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d);       // ... its K-concatenated form (variant 946128)
 // fused transposed conv (phase_cout > 0): GEMM column c -> (sub-pixel phase, output channel).  Each 64-column wave slice pairs
 // a cheap phase with an expensive one -- 32 columns of phase 0 (1 input shift) + 32 of phase 3 (4 shifts), or 1 + 2 (2 + 2) --
 // so that skipping the all-zero (shift, phase) weight blocks leaves every wave 4-5 of its 8 block-steps.

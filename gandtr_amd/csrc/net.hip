@@ -58,6 +58,9 @@ struct Op {
     bool has_ctf = false; PackedPhase ctf; size_t ctf_bias_off = 0;
     // f16c: Conv2d(k3, s2, p1) as a 2x2-shift conv over the virtual space-to-depth input (conv3x3_halo_c.hip, FORM 2): K = 4 shifts x 4 cin
     bool has_s2 = false; PackedPhase s2; size_t s2_bias_off = 0; int s2_cout_pad = 0;
+    // fp16 mode: a 1x1 expand conv whose residual is the output of a 1x1 projection conv (ResNet Bottleneck shortcut, stride 1 or 2) carries the two
+    // weight matrices K-concatenated (conv1x1_rb.hip, CAT form): kcat_ds = index of the projection op
+    int kcat_ds = -1; size_t kcat_frag_off = 0, kcat_bias_off = 0;
     // maxpool
     int k = 0, s = 0, p = 0;
     // gem
@@ -155,6 +158,7 @@ struct Step {
     bool bneck;      // CONV: first conv of a Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2 (identity shortcut) ...
     int bneck_ds;    // ... or {reduce, 1x1 projection shortcut} in either order at i, i + 1 (bneck_a / bneck_ds), i + 2 (3x3), i + 3 (expand + shortcut); -1: identity form
     int bneck_a;     // index of the block's reduce conv (identity form: the step itself)
+    bool kcat;       // CONV: expand conv that also computes its projection shortcut (Op::kcat_ds, whose own step is skipped)
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
@@ -210,7 +214,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -461,6 +465,22 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         plan.steps[i + 1].skip = true; plan.steps[i + 2].skip = true; plan.steps[i + 3].skip = true;
     }
 
+    // ---- pass 2d (fp16 mode): projection shortcut folded into the expand conv (K-concatenated 1x1, conv1x1_rb.hip) where the block did not fuse as a whole
+    for (int i = 0; i < nops && !net->precision; ++i) {
+        const Op& c = ops[i];
+        if (c.kind != OP_CONV || c.kcat_ds < 0) continue;
+        const int ids = c.kcat_ds;
+        const Op& ds = ops[ids];
+        if (plan.steps[i].skip || plan.steps[i].bneck || plan.steps[ids].skip || plan.steps[ids].bneck) continue;
+        if (plan.steps[i].norm_from >= 0 || plan.steps[ids].norm_from >= 0 || plan.steps[i].pool_into >= 0 || consumers[ds.out] != 1) continue;
+        ConvLaunch d{};
+        conv_geometry(net, c, c.phases[0], N, T[c.in], d);
+        d.w_frag = (const f16*)net; d.out = (f16*)net; d.in2 = (const f16*)net;            // non-null markers only
+        d.Kpad = c.cin_pad + ds.cin_pad; d.in2_cin = ds.cin_pad; d.in2_h = T[ds.in].H; d.in2_w = T[ds.in].W; d.in2_stride = ds.cd.stride;
+        if (!gdt_conv_1x1_cat_eligible(d)) continue;
+        plan.steps[i].kcat = true; plan.steps[ids].skip = true;
+    }
+
     // ---- pass 3: liveness + first-fit layout
     auto conv_input = [&](int i) { return plan.steps[i].norm_from >= 0 ? ops[plan.steps[i].norm_from].in : ops[i].in; };
     for (int i = 0; i < nops; ++i) {
@@ -468,6 +488,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         const int in = o.kind == OP_CONV ? conv_input(i) : o.in;
         if (in >= 0) T[in].last_use = i;
         if (o.res >= 0) T[o.res].last_use = i;
+        if (o.kind == OP_CONV && plan.steps[i].kcat) T[ops[o.kcat_ds].in].last_use = i;      // the expand conv reads the projection's input itself
         if (o.kind == OP_CONV && plan.steps[i].norm_from >= 0) {
             const Op& nj = ops[plan.steps[i].norm_from];          // the conv reads the residual and (wb) writes the norm's output tensor
             if (nj.res >= 0) T[nj.res].last_use = std::max(T[nj.res].last_use, i);
@@ -561,6 +582,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             if (t >= 0 && T[t].last_use == i && T[t].bytes) { arena.release(T[t].off, T[t].bytes); T[t].last_use = -2; }
         };
         maybe_free(o.kind == OP_CONV ? conv_input(i) : o.in); maybe_free(o.res);
+        if (o.kind == OP_CONV && st.kcat) maybe_free(ops[o.kcat_ds].in);
         if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) maybe_free(o.feats[k]);
         if (o.kind == OP_CONV && st.norm_from >= 0) { maybe_free(ops[st.norm_from].res); maybe_free(ops[st.norm_from].out); }
         if (o.out >= 0 && T[o.out].last_use == -1 && T[o.out].bytes) arena.release(T[o.out].off, T[o.out].bytes);   // never consumed
@@ -1049,9 +1071,55 @@ int gdt_net_hed_head(gdt_net* net, const int* feature_tensors, const float* cons
     return GDT_OK;
 }
 
+// fp16 mode: for every 1x1 conv c (stride 1, ReLU) whose residual is the output of a 1x1 projection conv ds (no ReLU, stride 1 or 2, no other consumer),
+// append the fragment-ordered K-concatenation [W_c | W_ds] and the summed bias to the weight blob (see Op::kcat_ds); whether a forward uses it is the
+// planner's decision per geometry
+static void build_kcat_weights(gdt_net* net) {
+    auto& ops = net->ops;
+    std::vector<int> consumers(net->tensors.size(), 0);
+    for (const Op& o : ops) {
+        if (o.in >= 0) ++consumers[o.in];
+        if (o.res >= 0) ++consumers[o.res];
+        if (o.kind == OP_HED) for (int k = 0; k < 5; ++k) ++consumers[o.feats[k]];
+    }
+    auto plain1x1 = [](const Op& o) {
+        return o.kind == OP_CONV && !o.cd.transposed && !o.cd.out_f32_nchw && !o.rowsplit && o.stats_for < 0 && o.phases.size() == 1 && o.phases[0].has_frag &&
+               o.has_bias && o.cd.kh == 1 && o.cd.kw == 1 && o.cd.pad == 0 && o.cin_pad % 64 == 0 && o.phases[0].Kpad == o.cin_pad && o.out >= 0;
+    };
+    for (size_t i = 0; i < ops.size(); ++i) {
+        Op& c = ops[i];
+        if (!plain1x1(c) || c.cd.stride != 1 || !c.cd.relu || c.res < 0 || c.cout_pad % 256 != 0) continue;
+        int ids = -1;
+        for (size_t j = 0; j < i; ++j) if (ops[j].out == c.res) ids = (int)j;
+        if (ids < 0) continue;
+        const Op& ds = ops[ids];
+        if (!plain1x1(ds) || ds.cd.relu || ds.res >= 0 || ds.cd.stride < 1 || ds.cd.stride > 2 || ds.cout_pad != c.cout_pad || ds.cd.cout != c.cd.cout || consumers[ds.out] != 1) continue;
+        const int K1 = c.cin_pad, K2 = ds.cin_pad, K = K1 + K2, nks = K / 16, cp = c.cout_pad;
+        if ((K / 64) % 2 != 0) continue;
+        const f16* w1 = (const f16*)(net->host_blob.data() + c.phases[0].w_off);
+        const f16* w2 = (const f16*)(net->host_blob.data() + ds.phases[0].w_off);
+        std::vector<f16> pf((size_t)cp * K);
+        for (int cb = 0; cb < cp / 32; ++cb)
+            for (int ks = 0; ks < nks; ++ks)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int co = cb * 32 + (ln & 31), k0 = ks * 16 + (ln >> 5) * 8;         // (a group of 8 k never straddles the two matrices: K1 % 64 == 0)
+                    const f16* src = k0 < K1 ? w1 + (size_t)co * K1 + k0 : w2 + (size_t)co * K2 + (k0 - K1);
+                    std::copy(src, src + 8, pf.data() + (((size_t)cb * nks + ks) * 64 + ln) * 8);
+                }
+        std::vector<float> bsum(cp);
+        const float* b1 = (const float*)(net->host_blob.data() + c.bias_off);
+        const float* b2 = (const float*)(net->host_blob.data() + ds.bias_off);
+        for (int k = 0; k < cp; ++k) bsum[k] = b1[k] + b2[k];
+        c.kcat_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));           // (invalidates w1 / w2 / b1 / b2: not used below)
+        c.kcat_bias_off = net->blob_append(bsum.data(), bsum.size() * sizeof(float));
+        c.kcat_ds = ids;
+    }
+}
+
 int gdt_net_finalize(gdt_net* net) {
     GDT_REQUIRE(net && !net->finalized, "net");
     GDT_REQUIRE(net->input_op == 0, "the first op must be gdt_net_input");
+    if (!net->precision) build_kcat_weights(net);
     const size_t bytes = align_up(net->host_blob.size());
     net->host_blob.resize(bytes);
     GDT_CHECK_HIP(hipMalloc((void**)&net->dev_blob, bytes));
@@ -1197,6 +1265,22 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     if (net->profiling) {      // the block's FLOPs and time are booked on its first conv
                         net->last_variant[stp.op] = 935000 + oc.cd.cout + (dsf ? 1 : 0);
                         for (int k = 1; k <= (dsf ? 3 : 2); ++k) { net->last_flops[stp.op] += net->last_flops[stp.op + k]; net->last_flops[stp.op + k] = 0.0; }
+                    }
+                    break;
+                }
+                if (stp.kcat) {                // expand conv + its projection shortcut as one K-concatenated 1x1 GEMM (conv1x1_rb.hip)
+                    const Op& ds = net->ops[o.kcat_ds];
+                    ConvLaunch d{};
+                    conv_geometry(net, o, o.phases[0], n, ti, d);
+                    d.in = tptr(o.in); d.out = tptr(o.out); d.zeros = zeros;
+                    d.w_frag = (const f16*)(net->dev_blob + o.kcat_frag_off);
+                    d.bias = (const float*)(net->dev_blob + o.kcat_bias_off);
+                    d.Kpad = o.cin_pad + ds.cin_pad; d.nk = d.Kpad / 64;
+                    d.in2 = tptr(ds.in); d.in2_cin = ds.cin_pad; d.in2_h = T[ds.in].H; d.in2_w = T[ds.in].W; d.in2_stride = ds.cd.stride;
+                    rc = gdt_launch_conv_1x1_rb(d, st);
+                    if (net->profiling) {
+                        net->last_variant[stp.op] = 946128;
+                        net->last_flops[stp.op] += net->last_flops[o.kcat_ds]; net->last_flops[o.kcat_ds] = 0.0;
                     }
                     break;
                 }

@@ -112,3 +112,38 @@ def test_fused_bottleneck_projection_shortcut(cuda_device, projection_first):
     print("fused bottleneck with projection shortcut: %.2e of fp64" % err)
     assert err < 1.5e-3, err
     assert torch.equal(outs[taps[1]], net.forward(xi.to(cuda_device))[taps[1]])
+
+
+@pytest.mark.parametrize("stride,cin,mid,C,n,h,w", [(2, 256, 128, 512, 2, 64, 64), (2, 512, 256, 1024, 1, 64, 64), (1, 512, 128, 512, 1, 40, 52)])
+def test_projection_shortcut_folded_into_the_expand_conv(cuda_device, stride, cin, mid, C, n, h, w):
+    """first block of a ResNet stage (torchvision `downsample`, stride on the 3x3 conv): where the block does not run as one launch, the
+    1x1 projection of the input is accumulated by the expand conv itself -- ONE GEMM over the K-concatenated weights [W_e | W_d], the
+    second operand read at the stride-2 pixels of x (conv1x1_rb.hip, CAT form; the projected tensor is never written).  Against fp64 on
+    the same fp16 tensors, ragged M (40 x 52 at batch 1), and that this kernel is the one that ran."""
+    net = HipNet(cuda_device, "f16")
+    t = net.input(3)
+    x = net.conv(t, _g("w0", (cin, 3, 1, 1), 0.5), _g("b0", (cin,), 0.3), relu=True)
+    wr, br = _g("wr", (mid, cin, 1, 1), cin ** -0.5), _g("br", (mid,), 0.2)
+    wd, bd = _g("wd", (C, cin, 1, 1), cin ** -0.5), _g("bd", (C,), 0.2)
+    w3, b3 = _g("w3", (mid, mid, 3, 3), (9 * mid) ** -0.5), _g("b3", (mid,), 0.2)
+    we, be = _g("we", (C, mid, 1, 1), mid ** -0.5), _g("be", (C,), 0.2)
+    sc = net.conv(x, wd, bd, stride=stride)
+    r = net.conv(x, wr, br, relu=True)
+    t3 = net.conv(r, w3, b3, stride=stride, pad=1, relu=True)
+    y = net.conv(t3, we, be, relu=True, residual=sc)
+    taps = [net.output_nchw(x), net.output_nchw(t3), net.output_nchw(y)]
+    net.finalize()
+    xi = synth.synth_input(7, (n, 3, h, w))
+    net.set_profiling(True)
+    outs = net.forward(xi.to(cuda_device))
+    torch.cuda.synchronize()
+    variants = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert 946128 in variants, variants
+    xin, t3v = outs[taps[0]].double().cpu(), outs[taps[1]].double().cpu()
+    ref = F.relu(F.conv2d(t3v, we.double(), be.double()) + F.conv2d(xin, wd.double(), bd.double(), stride=stride))
+    got = outs[taps[2]].double().cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print("expand conv + projection shortcut (stride %d): %.2e of fp64 (fp16 output rounding 4.9e-4)" % (stride, err))
+    assert err < 1e-3, err
+    assert torch.equal(outs[taps[2]], net.forward(xi.to(cuda_device))[taps[2]])
