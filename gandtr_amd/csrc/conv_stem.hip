@@ -283,6 +283,150 @@ int launch_stem(const ConvLaunch& d, hipStream_t stream) {
     return GDT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// ResNet stem, direct form (fp16 mode): Conv2d(3, 64, 7, stride 2, pad 3) + folded BN + ReLU straight from the caller's fp32 NCHW image --
+// the input pack kernel (0.26 ms per 32 x 1024^2 batch, a 537 MB tensor written and read back) is gone -- with a denser K packing:
+//   * an LDS word holds TWO horizontally adjacent pixels x 4 channel slots (3 real): word[hy][hx] = {pixel hx, pixel hx + 1}.  One MFMA k-step
+//     (16) = four taps of one kernel row: lanes fh = 0 read the word at column 2 ox + 4 h (taps 4h, 4h + 1), lanes fh = 1 the word at
+//     2 ox + 4 h + 2 (taps 4h + 2, 4h + 3); a kernel row is two k-steps (the eighth tap has zero weights): 14 k-steps instead of 25;
+//   * the halo (21 x 70 pixels) is fetched as three coalesced fp32 loads per pixel, per-channel affine of the input op applied (the same
+//     expression as the pack kernel: identical bits), rounded to fp16 and written twice (as the low half of its own word and the high half of
+//     its left neighbour's); the loads of the NEXT tile are issued before the MFMAs of this one and land under them and the epilogue.
+// Everything else (swapped operands, wave-private transpose patch, 128-byte line stores) is the fp16 stem above.
+constexpr int SP_HH = 21, SP_HW = 70, SP_PIX = SP_HH * SP_HW;                 // halo of an 8 x 32 output tile (+ one column for the pair words)
+constexpr int SP_ROUNDS = (SP_PIX + NT - 1) / NT;                              // 6
+constexpr int SP_NKS = 14;
+constexpr int SP_WBYTES = SP_NKS * 2 * 1024, SP_HBYTES = (SP_PIX * 16 + 1023) / 1024 * 1024;
+constexpr int SP_LDS = SP_WBYTES + SP_HBYTES + NWAVE * PATCH_BYTES;
+
+struct StemPairArgs { const float* x; int C; int perm[4]; float scale[4], shift[4]; };
+
+__global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch d, const StemPairArgs a, const int ntiles) {
+    constexpr int RPW = 2, TH = RPW * NWAVE, HW = SP_HW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wlds = smem;
+    char* hbuf = smem + SP_WBYTES;
+    char* pbuf = hbuf + SP_HBYTES;                // transpose patches (disjoint from the halo: the next halo is written while waves may still store)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tiles_x = (d.OW + TW - 1) / TW, tiles_y = (d.OH + TH - 1) / TH, tpi = tiles_x * tiles_y;
+    const int per_xcd = (ntiles + 7) >> 3, SS = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int span_lo = xcd * per_xcd, span_hi = min(span_lo + per_xcd, ntiles);
+    int tile = span_lo + slot;
+    if (tile >= span_hi) return;
+    for (int i = tid; i < SP_WBYTES / 16; i += NT) *(float4*)(wlds + i * 16) = *(const float4*)((const char*)d.w_frag + i * 16);
+    for (int i = tid; i < SP_HBYTES / 16; i += NT) *(float4*)(hbuf + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const long plane = (long)d.H * d.W;
+    float pv[SP_ROUNDS][3];       // raw loads: nothing may consume them before store_halo (a use right behind its load is a full-latency wait per load)
+    unsigned pin = 0;             // bit j: the pixel of round j lies inside the image
+    auto load_halo = [&](int t) {
+        const int n = t / tpi, r = t - n * tpi;
+        const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+        const float* img = a.x + (long)n * a.C * plane;
+#pragma unroll
+        for (int j = 0; j < SP_ROUNDS; ++j) {
+            const int p = min(j * NT + tid, SP_PIX - 1);
+            const int hy = p / HW, hx = p - hy * HW;
+            const int iy = y0 * 2 - 3 + hy, ix = x0 * 2 - 3 + hx;
+            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+            const long off = (long)min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1);
+            pin = j == 0 ? (unsigned)inb : pin | ((unsigned)inb << j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pv[j][c] = img[(long)a.perm[c] * plane + off];
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < SP_ROUNDS; ++j) {
+            const int p = j * NT + tid;
+            if (p < SP_PIX) {
+                const int hy = p / HW, hx = p - hy * HW;
+                const bool inb = (pin >> j) & 1u;
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = (inb && c < a.C) ? pv[j][c] * a.scale[c] + a.shift[c] : 0.f;       // zero padding is applied to the TRANSFORMED image
+                f16x4 h; h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)0.f;
+                *(f16x4*)(hbuf + p * 16) = h;
+                if (hx > 0) *(f16x4*)(hbuf + p * 16 - 8) = h;
+            }
+        }
+    };
+    const int a_lane = ((wave * RPW * 2) * HW + fr * 2 + 2 * fh) * 16;
+    float4 bvs[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bvs[j][g] = d.bias ? *(const float4*)(d.bias + j * 32 + 8 * g + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    load_halo(tile);
+    __syncthreads();                                   // weights + zeroed buffer
+    for (;;) {
+        const int n = tile / tpi, r = tile - n * tpi;
+        const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+        store_halo();
+        __syncthreads();
+        const int nxt = tile + SS;
+        if (nxt < span_hi) load_halo(nxt);             // lands under the MFMAs and the epilogue
+
+        f32x16 acc[RPW][2];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        {
+            constexpr int PF = 3;
+            f16x8 af[PF][RPW], bf[PF][2];
+            auto frags = [&](int ks, f16x8 (&av)[RPW], f16x8 (&bv)[2]) {
+                const int ty = ks >> 1, h = ks & 1;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) av[i] = *(const f16x8*)(hbuf + a_lane + ((i * 2 + ty) * HW + 4 * h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
+            };
+#pragma unroll
+            for (int p = 0; p < PF - 1; ++p) frags(p, af[p], bf[p]);
+#pragma unroll
+            for (int ks = 0; ks < SP_NKS; ++ks) {
+                if (ks + PF - 1 < SP_NKS) frags(ks + PF - 1, af[(ks + PF - 1) % PF], bf[(ks + PF - 1) % PF]);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: per 32-pixel row block through the wave's private patch (as the fp16 stem)
+        f16* patch = (f16*)(pbuf + wave * PATCH_BYTES);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = j * 32 + 8 * g + 4 * fh;
+                    const float4 bv = bvs[j][g];
+                    float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y, v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                    if (d.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                    f16x4 h; h[0] = (f16)v0; h[1] = (f16)v1; h[2] = (f16)v2; h[3] = (f16)v3;
+                    *(f16x4*)(patch + fr * CP + col) = h;
+                }
+            const int oy = y0 + wave * RPW + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, px = idx >> 3, ch = idx & 7;
+                const f16x8 v = *(const f16x8*)(patch + px * CP + ch * 8);
+                if ((oy < d.OH) & (x0 + px < d.OW)) *(f16x8*)(d.out + ((long)((n * d.OH + oy) * d.OW + x0 + px) * 64 + ch * 8)) = v;
+            }
+        }
+        __syncthreads();                               // every wave is done reading the halo
+        tile = nxt;
+        if (tile >= span_hi) break;
+    }
+}
+
 }  // namespace
 
 // 8-channel (image) input, exactly 64 output channels, fp16 NHWC output, 7x7 (stride 1 or 2, pad 3) or 3x3 (stride 1, pad 1);
@@ -321,4 +465,36 @@ bool gdt_conv_stem_c_eligible(const ConvLaunch& d) {
 int gdt_launch_conv_stem_c(const ConvLaunch& d, hipStream_t stream) {
     if (d.ntaps == 9) return launch_stem<3, 1, true>(d, stream);
     return d.sy == 1 ? launch_stem<7, 1, true>(d, stream) : launch_stem<7, 2, true>(d, stream);
+}
+
+
+// Direct form of the ResNet stem (see conv_stem_pair_kernel): the descriptor is the stem conv's (H, W = the image, w_frag = the pair-packed weights of
+// net.hip, fp16 NHWC output), x the caller's fp32 NCHW image with at most 3 channels, perm / scale / shift the input op's per-channel transform.
+bool gdt_conv_stem_pair_eligible(const ConvLaunch& d) {
+    static const int mode = [] { const char* e = getenv("GDT_CONV_STEM_PAIR"); return e ? atoi(e) : 1; }();
+    if (mode == 0 || !d.w_frag || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm || d.pool2 || d.stats || d.pad_reflect) return false;
+    if (d.ntaps != 49 || d.TW != 7 || d.dy0 != -3 || d.dx0 != -3 || d.sy != 2 || d.sx != 2 || d.dys != 1 || d.dxs != 1) return false;
+    if (d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0 || d.H < 8 || d.W < 8) return false;
+    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+}
+
+int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream) {
+    GDT_REQUIRE(x != nullptr && C >= 1 && C <= 3, "stem: 1..3 image channels");
+    static_assert(2 * SP_LDS <= 160 * 1024, "two workgroups per CU");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        GDT_CHECK_HIP(hipGetDevice(&dev));
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus / 8 * 8;
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+    }
+    StemPairArgs a;
+    a.x = x; a.C = C;
+    for (int c = 0; c < 4; ++c) { a.perm[c] = c < C ? perm[c] : 0; a.scale[c] = c < C ? scale[c] : 0.f; a.shift[c] = c < C ? shift[c] : 0.f; }
+    const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + 7) / 8);
+    const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
+    hipLaunchKernelGGL(conv_stem_pair_kernel, dim3(grid), dim3(NT), SP_LDS, stream, d, a, ntiles);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
 }

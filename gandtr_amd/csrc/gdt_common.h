@@ -118,6 +118,8 @@ int gdt_launch_conv_halo_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_igemm_rb_eligible(const ConvLaunch& d);      // conv_igemm_rb.hip (persistent implicit GEMM, variant 940000 + BN)
 int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* variant);
 int gdt_conv_igemm_rb_stats_sets(const ConvLaunch& d);
+bool gdt_conv_stem_pair_eligible(const ConvLaunch& d);    // conv_stem.hip, ResNet stem straight from the fp32 NCHW image (variant 951049)
+int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream);
 bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d);        // conv1x1_rb.hip (streaming 1x1 conv, variant 945128)
 int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d);       // ... its K-concatenated form (variant 946128)

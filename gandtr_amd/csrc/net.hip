@@ -32,6 +32,7 @@ struct PackedPhase {
     size_t w_lo_off = 0;              // f16x3 mode: offset of the low parts
     size_t w_frag_off = 0; bool has_frag = false;   // fp16 mode, 3x3 s1 p1: copy in MFMA B-fragment order (conv3x3_halo_rb.hip)
     size_t w_frag2_off = 0; bool has_aug = false;   // f16c stem: w_frag = augmented W1, w_frag2 = residual W2 (conv_stem.hip)
+    size_t w_pair_off = 0; bool has_pair = false;   // fp16 ResNet stem (7x7 s2): pair-word k order of conv_stem_pair_kernel
     size_t wc_off = 0, wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
@@ -159,6 +160,7 @@ struct Step {
     int bneck_ds;    // ... or {reduce, 1x1 projection shortcut} in either order at i, i + 1 (bneck_a / bneck_ds), i + 2 (3x3), i + 3 (expand + shortcut); -1: identity form
     int bneck_a;     // index of the block's reduce conv (identity form: the step itself)
     bool kcat;       // CONV: expand conv that also computes its projection shortcut (Op::kcat_ds, whose own step is skipped)
+    bool direct;     // INPUT + its only consumer, the ResNet stem conv: the conv reads the caller's fp32 NCHW image itself when no resize is asked (conv_stem_pair_kernel)
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
 };
 struct Plan { std::vector<Step> steps; size_t peak = 0; };
@@ -214,7 +216,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -479,6 +481,19 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
         d.Kpad = c.cin_pad + ds.cin_pad; d.in2_cin = ds.cin_pad; d.in2_h = T[ds.in].H; d.in2_w = T[ds.in].W; d.in2_stride = ds.cd.stride;
         if (!gdt_conv_1x1_cat_eligible(d)) continue;
         plan.steps[i].kcat = true; plan.steps[ids].skip = true;
+    }
+
+    // ---- pass 2e (fp16 mode): the ResNet stem straight from the caller's image (no input pack) -- decided here, taken by the executor when the call does not resize
+    if (!net->precision && nops >= 2 && ops[0].kind == OP_INPUT && ops[0].in_c <= 3 && consumers[ops[0].out] == 1) {
+        const int j = consumer_op[ops[0].out];
+        const Op& o = ops[j];
+        if (o.kind == OP_CONV && o.in == ops[0].out && o.res < 0 && o.phases.size() == 1 && o.phases[0].has_pair && !plan.steps[j].aug && plan.steps[j].norm_from < 0 &&
+            plan.steps[j].pool_into < 0 && o.stats_for < 0 && !plan.steps[j].skip && !plan.steps[j].bneck) {
+            ConvLaunch d{};
+            conv_geometry(net, o, o.phases[0], N, T[o.in], d);
+            d.w_frag = (const f16*)net; d.out = (f16*)net;                                 // non-null markers only
+            if (gdt_conv_stem_pair_eligible(d)) { plan.steps[0].direct = true; plan.steps[j].direct = true; }
+        }
     }
 
     // ---- pass 3: liveness + first-fit layout
@@ -833,6 +848,20 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                         }
             ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
             ph.has_frag = true;
+            if (cd.kh == 7 && cd.kw == 7 && cd.stride == 2 && cd.pad == 3 && !cd.pad_reflect && cd.cin <= 3) {
+                // conv_stem_pair_kernel: k-step ks = ty * 2 + h covers taps tx = 4h .. 4h + 3 of kernel row ty; lane (fh, fr) element e = tap 4h + 2fh + (e >> 2),
+                // channel slot e & 3 (3 real channels; tap 7 does not exist: zero)
+                std::vector<f16> pp((size_t)14 * 2 * 64 * 8, (f16)0.f);
+                for (int ks = 0; ks < 14; ++ks)
+                    for (int j = 0; j < 2; ++j)
+                        for (int ln = 0; ln < 64; ++ln)
+                            for (int e = 0; e < 8; ++e) {
+                                const int ty = ks >> 1, tx = 4 * (ks & 1) + 2 * (ln >> 5) + (e >> 2), ch = e & 3;
+                                if (tx < 7 && ch < cd.cin) pp[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = pk[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + (ty * 7 + tx) * 8 + ch];
+                            }
+                ph.w_pair_off = net->blob_append(pp.data(), pp.size() * sizeof(f16));
+                ph.has_pair = true;
+            }
         }
     };
 
@@ -1246,6 +1275,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
+                if (stp.direct && !resize) break;            // the stem conv reads x itself
                 rc = gdt_k_pack_input(x, tptr(o.out), stp.aug ? 2 : f32, n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
                 break;
             }
@@ -1266,6 +1296,17 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         net->last_variant[stp.op] = 935000 + oc.cd.cout + (dsf ? 1 : 0);
                         for (int k = 1; k <= (dsf ? 3 : 2); ++k) { net->last_flops[stp.op] += net->last_flops[stp.op + k]; net->last_flops[stp.op + k] = 0.0; }
                     }
+                    break;
+                }
+                if (stp.direct && rh == h && rw == w) {      // ResNet stem from the fp32 NCHW image (conv_stem.hip, pair-word form)
+                    const Op& oi = net->ops[0];
+                    ConvLaunch d{};
+                    conv_geometry(net, o, o.phases[0], n, ti, d);
+                    d.out = tptr(o.out); d.zeros = zeros;
+                    d.w_frag = (const f16*)(net->dev_blob + o.phases[0].w_pair_off);
+                    d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
+                    rc = gdt_launch_conv_stem_pair(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, st);
+                    if (net->profiling) net->last_variant[stp.op] = 951049;
                     break;
                 }
                 if (stp.kcat) {                // expand conv + its projection shortcut as one K-concatenated 1x1 GEMM (conv1x1_rb.hip)
