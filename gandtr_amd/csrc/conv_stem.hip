@@ -326,16 +326,17 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
         const int n = t / tpi, r = t - n * tpi;
         const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
         const float* img = a.x + (long)n * a.C * plane;
-#pragma unroll
+        const float* pl[3] = {img + (long)a.perm[0] * plane, img + (long)a.perm[1] * plane, img + (long)a.perm[2] * plane};      // uniform bases: the loads take the
+#pragma unroll                                                                                                              //  scalar-base + 32-bit lane offset form
         for (int j = 0; j < SP_ROUNDS; ++j) {
             const int p = min(j * NT + tid, SP_PIX - 1);
             const int hy = p / HW, hx = p - hy * HW;
             const int iy = y0 * 2 - 3 + hy, ix = x0 * 2 - 3 + hx;
             const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
-            const long off = (long)min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1);
+            const unsigned off = (unsigned)(min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1));
             pin = j == 0 ? (unsigned)inb : pin | ((unsigned)inb << j);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pv[j][c] = img[(long)a.perm[c] * plane + off];
+            for (int c = 0; c < 3; ++c) pv[j][c] = pl[c][off];
         }
     };
     auto store_halo = [&]() {
@@ -427,6 +428,208 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
     }
 }
 
+// ... and with the MaxPool2d(3, stride 2, pad 1) that follows the ResNet stem fused in: the 1.07 GB stem output of a 32 x 1024^2 batch is never written.
+// A workgroup owns 7 x 15 POOLED pixels = conv rows 2 py0 - 1 .. + 15 (four per wave) x conv columns 2 px0 - 1 .. + 31: neighbouring tiles recompute
+// one conv row / column of overlap (16 / 14 x 32 / 30 = 1.22x the MFMAs, which are not the bound).  After bias + ReLU (conv samples outside the conv
+// output count as 0 -- equivalent to the pool's -inf padding behind a ReLU): max over 3 columns by two wave-shift DPP steps in the accumulator
+// registers (lane = conv column), max over 3 rows inside the wave, plus ONE row fetched from the next wave through LDS for the wave's second
+// pooled row; even-column lanes then go through the wave's transpose patch and leave as 128-byte lines.  (Rounding to fp16 commutes with max.)
+#ifndef GDT_STEM_POOL_EARLY_PREFETCH
+#define GDT_STEM_POOL_EARLY_PREFETCH 0      // 1: next tile's loads before the MFMAs (14 spilled registers; measured 0.58 vs 0.55 ms)
+#endif
+constexpr int SQ_HH = 37, SQ_PIX = SQ_HH * SP_HW, SQ_ROUNDS = (SQ_PIX + NT - 1) / NT;      // halo of 16 x 32 conv outputs; 11 loader rounds
+constexpr int SQ_HBYTES = (SQ_PIX * 16 + 1023) / 1024 * 1024;
+constexpr int SQ_LDS = SP_WBYTES + SQ_HBYTES + 256;                                          // + the bias vector
+static_assert(SQ_HBYTES >= NWAVE * 2048 + NWAVE * 16 * CP * 2, "exchange rows and patches alias the consumed halo");
+
+__global__ __launch_bounds__(NT, 2) void conv_stem_pair_pool_kernel(const ConvLaunch d, const StemPairArgs a, const int ntiles, const int PH, const int PW) {
+    constexpr int RPW = 4, HW = SP_HW, PR = 7, PC = 15;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wlds = smem;
+    char* hbuf = smem + SP_WBYTES;
+    float* blds = (float*)(hbuf + SQ_HBYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tiles_x = (PW + PC - 1) / PC, tiles_y = (PH + PR - 1) / PR, tpi = tiles_x * tiles_y;
+    const int per_xcd = (ntiles + 7) >> 3, SS = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int span_lo = xcd * per_xcd, span_hi = min(span_lo + per_xcd, ntiles);
+    int tile = span_lo + slot;
+    if (tile >= span_hi) return;
+    for (int i = tid; i < SP_WBYTES / 16; i += NT) *(float4*)(wlds + i * 16) = *(const float4*)((const char*)d.w_frag + i * 16);
+    if (tid < 64) blds[tid] = d.bias ? d.bias[tid] : 0.f;
+
+    const long plane = (long)d.H * d.W;
+    float pv[SQ_ROUNDS][3];
+    unsigned pin = 0;
+    auto load_halo = [&](int t) {
+        const int n = t / tpi, r = t - n * tpi;
+        const int cy0 = (r / tiles_x) * (2 * PR) - 1, cx0 = (r % tiles_x) * (2 * PC) - 1;
+        const float* img = a.x + (long)n * a.C * plane;
+        const float* pl[3] = {img + (long)a.perm[0] * plane, img + (long)a.perm[1] * plane, img + (long)a.perm[2] * plane};      // uniform bases: the loads take the
+#pragma unroll                                                                                                              //  scalar-base + 32-bit lane offset form
+        for (int j = 0; j < SQ_ROUNDS; ++j) {
+            const int p = min(j * NT + tid, SQ_PIX - 1);
+            const int hy = p / HW, hx = p - hy * HW;
+            const int iy = cy0 * 2 - 3 + hy, ix = cx0 * 2 - 3 + hx;
+            const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
+            const unsigned off = (unsigned)(min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1));
+            pin = j == 0 ? (unsigned)inb : pin | ((unsigned)inb << j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pv[j][c] = pl[c][off];
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < SQ_ROUNDS; ++j) {
+            const int p = j * NT + tid;
+            if (p < SQ_PIX) {
+                const int hy = p / HW, hx = p - hy * HW;
+                const bool inb = (pin >> j) & 1u;
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] = (inb && c < a.C) ? pv[j][c] * a.scale[c] + a.shift[c] : 0.f;
+                f16x4 h; h[0] = (f16)v[0]; h[1] = (f16)v[1]; h[2] = (f16)v[2]; h[3] = (f16)0.f;
+                *(f16x4*)(hbuf + p * 16) = h;
+                // the high half of the left neighbour's word; the last word of a row keeps a (finite) stale high half: it only meets tap 7's zero weights
+                if (hx > 0) *(f16x4*)(hbuf + p * 16 - 8) = h;
+            }
+        }
+    };
+    const int a_lane = ((wave * RPW * 2) * HW + fr * 2 + 2 * fh) * 16;
+    char* xrow = hbuf;                                     // [wave][16 pooled columns][64 channels] fp16: every wave's first conv row after the column max
+    f16* patch = (f16*)(hbuf + NWAVE * 2048) + wave * (16 * CP);
+    for (int i = tid; i < SQ_HBYTES / 16; i += NT) *(float4*)(hbuf + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    load_halo(tile);
+    __syncthreads();
+    for (;;) {
+        const int n = tile / tpi, r = tile - n * tpi;
+        const int py0 = (r / tiles_x) * PR, px0 = (r % tiles_x) * PC;
+        const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
+        store_halo();
+        __syncthreads();
+        const int nxt = tile + SS;
+#if GDT_STEM_POOL_EARLY_PREFETCH
+        if (nxt < span_hi) load_halo(nxt);
+#endif
+
+        f32x16 acc[RPW][2];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {          // the accumulators start from the bias: register 4g + e of lane (fr, fh) is channel j * 32 + 8g + 4fh + e
+                    const float4 bv = *(const float4*)(blds + j * 32 + 8 * g + 4 * fh);
+                    acc[i][j][4 * g] = bv.x; acc[i][j][4 * g + 1] = bv.y; acc[i][j][4 * g + 2] = bv.z; acc[i][j][4 * g + 3] = bv.w;
+                }
+        {
+            constexpr int PF = 2;
+            f16x8 af[PF][RPW], bf[PF][2];
+            auto frags = [&](int ks, f16x8 (&av)[RPW], f16x8 (&bv)[2]) {
+                const int ty = ks >> 1, h = ks & 1;
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) av[i] = *(const f16x8*)(hbuf + a_lane + ((i * 2 + ty) * HW + 4 * h) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
+            };
+            frags(0, af[0], bf[0]);
+#pragma unroll
+            for (int ks = 0; ks < SP_NKS; ++ks) {
+                if (ks + 1 < SP_NKS) frags(ks + 1, af[(ks + 1) % PF], bf[(ks + 1) % PF]);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks % PF][j], af[ks % PF][i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                               // every wave is done reading the halo: its bytes now hold the exchange rows and the patches
+        // ---- ReLU, validity mask, rounding to fp16 pairs (64 registers instead of 128; rounding commutes with max), then the column max on the pairs:
+        // lane fr = conv column cx0 + fr; two wave-shift steps give max over columns fr, fr + 1, fr + 2 (used at even fr <= 28)
+        typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 hq[RPW][2][8];
+        {
+            const bool col_ok = (unsigned)(cx0 + fr) < (unsigned)d.OW;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const bool ok = col_ok & ((unsigned)(cy0 + wave * RPW + i) < (unsigned)d.OH);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        // one packed convert, ReLU and mask on the pair (three instructions per two values).  (Not inline asm: the hazard
+                        // recogniser does not see an asm statement's read of a register the MFMAs just before it are still writing.)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 pr2 = {acc[i][j][2 * k], acc[i][j][2 * k + 1]};
+                        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(pr2, f16x2));
+                        f16x2 h = __builtin_bit_cast(f16x2, ok ? pk : 0u);
+                        const f16x2 zero2 = {(f16)0.f, (f16)0.f};
+                        if (d.relu) h = __builtin_elementwise_max(h, zero2);
+                        hq[i][j][k] = h;
+                    }
+            }
+        }
+#if !GDT_STEM_POOL_EARLY_PREFETCH
+        if (nxt < span_hi) load_halo(nxt);             // (here, not before the MFMAs: the accumulators are dead now and the 33 halo registers fit; the rest of the epilogue covers the latency)
+#endif
+        auto shl1h = [](f16x2 v) -> f16x2 { return __builtin_bit_cast(f16x2, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); };
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f16x2 t = __builtin_elementwise_max(hq[i][j][k], shl1h(hq[i][j][k]));
+                    hq[i][j][k] = __builtin_elementwise_max(t, shl1h(t));
+                }
+        // ---- the wave's first row goes to LDS for the wave above it (pair 2g, 2g + 1 of block j = channels j * 32 + 8g + 4fh .. + 3)
+        const bool writer = (fr & 1) == 0;
+        const int pc = fr >> 1;
+        auto quad = [](f16x2 lo, f16x2 hi) -> uint2 { return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)); };
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *(uint2*)(xrow + wave * 2048 + (pc * 64 + j * 32 + 8 * g + 4 * fh) * 2) = quad(hq[0][j][2 * g], hq[0][j][2 * g + 1]);
+        }
+        __syncthreads();
+        // ---- row max + store: pooled rows 2 wave (conv rows 0, 1, 2 of the wave) and 2 wave + 1 (rows 2, 3 and row 0 of the next wave; none for the last wave)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int pr = 2 * wave + sidx;
+            const int py = py0 + pr;
+            const bool row_ok = (pr < PR) & (py < PH);       // (wave-uniform)
+            if (writer) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x2 m0, m1;
+                        if (sidx == 0) {
+                            m0 = __builtin_elementwise_max(__builtin_elementwise_max(hq[0][j][2 * g], hq[1][j][2 * g]), hq[2][j][2 * g]);
+                            m1 = __builtin_elementwise_max(__builtin_elementwise_max(hq[0][j][2 * g + 1], hq[1][j][2 * g + 1]), hq[2][j][2 * g + 1]);
+                        } else {
+                            const uint2 nx = *(const uint2*)(xrow + min(wave + 1, NWAVE - 1) * 2048 + (pc * 64 + j * 32 + 8 * g + 4 * fh) * 2);
+                            m0 = __builtin_elementwise_max(__builtin_elementwise_max(hq[2][j][2 * g], hq[3][j][2 * g]), __builtin_bit_cast(f16x2, nx.x));
+                            m1 = __builtin_elementwise_max(__builtin_elementwise_max(hq[2][j][2 * g + 1], hq[3][j][2 * g + 1]), __builtin_bit_cast(f16x2, nx.y));
+                        }
+                        *(uint2*)(patch + pc * CP + j * 32 + 8 * g + 4 * fh) = quad(m0, m1);
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = lane + 64 * q, px = idx >> 3, ch = idx & 7;
+                const f16x8 v = *(const f16x8*)(patch + px * CP + ch * 8);
+                if (row_ok & (px < PC) & (px0 + px < PW)) *(f16x8*)(d.out + ((long)((n * PH + py) * PW + px0 + px) * 64 + ch * 8)) = v;
+            }
+        }
+        __syncthreads();                               // exchange rows / patches are dead: the next halo may be written
+        tile = nxt;
+        if (tile >= span_hi) break;
+    }
+}
+
 }  // namespace
 
 // 8-channel (image) input, exactly 64 output channels, fp16 NHWC output, 7x7 (stride 1 or 2, pad 3) or 3x3 (stride 1, pad 1);
@@ -498,3 +701,28 @@ int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const 
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
+
+// ... with the following MaxPool2d(3, 2, 1) fused: d.out is the POOLED tensor [N][PH][PW][64]
+int gdt_launch_conv_stem_pair_pool(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, int PH, int PW,
+                                   hipStream_t stream) {
+    GDT_REQUIRE(x != nullptr && C >= 1 && C <= 3, "stem: 1..3 image channels");
+    GDT_REQUIRE(PH == (d.OH - 1) / 2 + 1 && PW == (d.OW - 1) / 2 + 1, "stem: pooled size");
+    static_assert(2 * SQ_LDS <= 160 * 1024, "two workgroups per CU");
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        GDT_CHECK_HIP(hipGetDevice(&dev));
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cus = cus / 8 * 8;
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS));
+    }
+    StemPairArgs a;
+    a.x = x; a.C = C;
+    for (int c = 0; c < 4; ++c) { a.perm[c] = c < C ? perm[c] : 0; a.scale[c] = c < C ? scale[c] : 0.f; a.shift[c] = c < C ? shift[c] : 0.f; }
+    const int ntiles = d.N * ((PW + 14) / 15) * ((PH + 6) / 7);
+    const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
+    hipLaunchKernelGGL(conv_stem_pair_pool_kernel, dim3(grid), dim3(NT), SQ_LDS, stream, d, a, ntiles, PH, PW);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+

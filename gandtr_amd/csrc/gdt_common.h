@@ -120,6 +120,7 @@ int gdt_launch_conv_igemm_rb(const ConvLaunch& d, hipStream_t stream, int* varia
 int gdt_conv_igemm_rb_stats_sets(const ConvLaunch& d);
 bool gdt_conv_stem_pair_eligible(const ConvLaunch& d);    // conv_stem.hip, ResNet stem straight from the fp32 NCHW image (variant 951049)
 int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream);
+int gdt_launch_conv_stem_pair_pool(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, int PH, int PW, hipStream_t stream);   // ... + MaxPool2d(3, 2, 1) (variant 952049)
 bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d);        // conv1x1_rb.hip (streaming 1x1 conv, variant 945128)
 int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d);       // ... its K-concatenated form (variant 946128)

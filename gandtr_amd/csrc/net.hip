@@ -210,7 +210,8 @@ void s2_geometry(const gdt_net* net, const Op& o, int n, const Tensor& ti, ConvL
 }
 
 // shape inference, fusion decisions and workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
-int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
+// direct_ok: the call does not resize its input (forward knows; the size queries plan the general case, whose footprint is the larger one)
+int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = false) {
     auto& T = net->tensors;
     const auto& ops = net->ops;
     const int nops = (int)ops.size();
@@ -484,7 +485,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
     }
 
     // ---- pass 2e (fp16 mode): the ResNet stem straight from the caller's image (no input pack) -- decided here, taken by the executor when the call does not resize
-    if (!net->precision && nops >= 2 && ops[0].kind == OP_INPUT && ops[0].in_c <= 3 && consumers[ops[0].out] == 1) {
+    if (direct_ok && !net->precision && nops >= 2 && ops[0].kind == OP_INPUT && ops[0].in_c <= 3 && consumers[ops[0].out] == 1) {
         const int j = consumer_op[ops[0].out];
         const Op& o = ops[j];
         if (o.kind == OP_CONV && o.in == ops[0].out && o.res < 0 && o.phases.size() == 1 && o.phases[0].has_pair && !plan.steps[j].aug && plan.steps[j].norm_from < 0 &&
@@ -492,7 +493,15 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             ConvLaunch d{};
             conv_geometry(net, o, o.phases[0], N, T[o.in], d);
             d.w_frag = (const f16*)net; d.out = (f16*)net;                                 // non-null markers only
-            if (gdt_conv_stem_pair_eligible(d)) { plan.steps[0].direct = true; plan.steps[j].direct = true; }
+            if (gdt_conv_stem_pair_eligible(d)) {
+                plan.steps[0].direct = true; plan.steps[j].direct = true;
+                // ... and the MaxPool2d(3, 2, 1) behind it, when it is the stem's only consumer: the stem launch writes the pooled tensor
+                static const bool pool_ok = [] { const char* e = getenv("GDT_CONV_STEM_POOL"); return !e || atoi(e) != 0; }();
+                const int jp = consumers[o.out] == 1 ? consumer_op[o.out] : -1;
+                if (pool_ok && jp >= 0 && ops[jp].kind == OP_MAXPOOL && ops[jp].k == 3 && ops[jp].s == 2 && ops[jp].p == 1 && o.cd.relu && o.slot < 0) {
+                    plan.steps[j].pool_into = jp; plan.steps[jp].skip = true;
+                }
+            }
         }
     }
 
@@ -523,7 +532,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan) {
             t.off = arena.alloc(t.bytes);
         };
         switch (o.kind) {
-            case OP_INPUT: alloc_out(); break;
+            case OP_INPUT: if (!st.direct) alloc_out(); break;      // (direct: the stem conv reads the caller's image, the packed tensor never exists)
             case OP_CONV: {
                 const Tensor& ti = T[o.in];       // same size as the raw tensor when the norm is folded
                 const int oh = conv_out_dim(o.cd, ti.H, o.cd.kh);
@@ -1181,10 +1190,12 @@ int gdt_net_output_shape(gdt_net* net, int slot, int n, int rh, int rw, int* dim
 
 int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes) {
     GDT_REQUIRE(net && bytes && n >= 1 && rh >= 1 && rw >= 1, "geometry");
-    Plan plan;
+    Plan plan, direct;
     int rc = make_plan(net, n, rh, rw, plan);
     if (rc != GDT_OK) return rc;
-    *bytes = plan.peak + ALIGN;
+    rc = make_plan(net, n, rh, rw, direct, true);          // a call that does not resize may take the direct-stem plan: another layout, either may be the larger
+    if (rc != GDT_OK) return rc;
+    *bytes = std::max(plan.peak, direct.peak) + ALIGN;
     return GDT_OK;
 }
 
@@ -1251,7 +1262,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     GDT_REQUIRE((long)n * rh * rw < (1l << 31) && (long)n * h * w < (1l << 31), "N*H*W must stay below 2^31");
     for (int i = 0; i < n_outputs; ++i) GDT_REQUIRE(outputs[i] != nullptr, "null output buffer");
     Plan plan;
-    int rc = make_plan(net, n, rh, rw, plan);
+    int rc = make_plan(net, n, rh, rw, plan, rh == h && rw == w);
     if (rc != GDT_OK) return rc;
     if (plan.peak + ALIGN > workspace_bytes || !workspace) {
         gdt_set_error("workspace too small: need " + std::to_string(plan.peak + ALIGN) + " bytes, got " + std::to_string(workspace_bytes));
@@ -1275,7 +1286,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
-                if (stp.direct && !resize) break;            // the stem conv reads x itself
+                if (stp.direct) break;                       // the stem conv reads x itself (planned only for calls that do not resize)
                 rc = gdt_k_pack_input(x, tptr(o.out), stp.aug ? 2 : f32, n, o.in_c, h, w, rh, rw, rscale, resize, o.perm, o.scale, o.shift, st);
                 break;
             }
@@ -1298,15 +1309,22 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     }
                     break;
                 }
-                if (stp.direct && rh == h && rw == w) {      // ResNet stem from the fp32 NCHW image (conv_stem.hip, pair-word form)
+                if (stp.direct) {              // ResNet stem from the fp32 NCHW image (conv_stem.hip, pair-word form), with the max-pool behind it when planned so
                     const Op& oi = net->ops[0];
                     ConvLaunch d{};
                     conv_geometry(net, o, o.phases[0], n, ti, d);
-                    d.out = tptr(o.out); d.zeros = zeros;
+                    d.zeros = zeros;
                     d.w_frag = (const f16*)(net->dev_blob + o.phases[0].w_pair_off);
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.bias_off) : nullptr;
-                    rc = gdt_launch_conv_stem_pair(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, st);
-                    if (net->profiling) net->last_variant[stp.op] = 951049;
+                    if (stp.pool_into >= 0) {
+                        const Tensor& tp = T[net->ops[stp.pool_into].out];
+                        d.out = tptr(net->ops[stp.pool_into].out);
+                        rc = gdt_launch_conv_stem_pair_pool(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, tp.H, tp.W, st);
+                    } else {
+                        d.out = tptr(o.out);
+                        rc = gdt_launch_conv_stem_pair(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, st);
+                    }
+                    if (net->profiling) net->last_variant[stp.op] = stp.pool_into >= 0 ? 952049 : 951049;
                     break;
                 }
                 if (stp.kcat) {                // expand conv + its projection shortcut as one K-concatenated 1x1 GEMM (conv1x1_rb.hip)
