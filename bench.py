@@ -132,8 +132,14 @@ def kernel_name(variant):
         return "conv3x3_halo_rb_kernel<256>[transposed]"
     if variant >= 955000:
         return "conv_stem_kernel<%d taps>[f16c]" % (variant - 955000)
+    if variant == 952049:
+        return "conv_stem_pair_pool_kernel"                # ResNet stem from the fp32 image + MaxPool2d(3, 2, 1)
+    if variant == 951049:
+        return "conv_stem_pair_kernel"
     if variant >= 950000:
         return "conv_stem_kernel<%d taps>" % (variant - 950000)
+    if variant == 946128:
+        return "conv1x1_rb_kernel[+projection]"            # expand conv + projection shortcut, K-concatenated
     if variant >= 945000:
         return "conv1x1_rb_kernel"
     if variant >= 940000:

@@ -304,3 +304,50 @@ def test_input_perm_affine(cuda_device):
     got = net.forward(x.to(cuda_device))[o].cpu()[:, :3]
     ref = x[:, [2, 1, 0]] * torch.tensor([0.5, 2.0, 1.0])[None, :, None, None] + torch.tensor([0.1, -0.2, 0.3])[None, :, None, None]
     assert float((got - ref).abs().max()) < 4e-3
+
+
+@pytest.mark.parametrize("pool,n,h,w", [(True, 1, 530, 614), (True, 3, 224, 448), (False, 1, 530, 614), (True, 2, 512, 512)])
+def test_resnet_stem_from_the_fp32_image(cuda_device, pool, n, h, w):
+    """conv_stem_pair[_pool]_kernel: Conv2d(3, 64, 7, stride 2, pad 3) + BN + ReLU (+ MaxPool2d(3, 2, 1)) read straight from the caller's fp32
+    NCHW image with the input op's channel permutation / scale / shift applied in the loader (no pack launch, no packed tensor), ragged tile
+    edges in both directions (pooled 133 x 154 is not a multiple of the 7 x 15 tile), against fp64 on the fp16-rounded transformed image; and
+    that these are the kernels that ran.  A call that resizes (multi-scale pyramid) must take the general path and agree with torch as well."""
+    from gandtr_amd.engine import HipNet
+    perm, scale, shift = [2, 1, 0], [1.7, 0.6, -1.2], [0.3, -0.2, 0.1]
+    net = HipNet(cuda_device)
+    t = net.input(3, perm=perm, scale=scale, shift=shift)
+    wt = synth._normal(0, "ws", (64, 3, 7, 7), math.sqrt(2.0 / 147))
+    bnp = (synth._uniform(0, "g", (64,), 0.5, 1.5), synth._normal(0, "be", (64,), 0.2), synth._normal(0, "m", (64,), 0.2), synth._uniform(0, "v", (64,), 0.5, 1.5))
+    o = net.conv(t, wt, None, bn=bnp, stride=2, pad=3, relu=True)
+    if pool:
+        o = net.maxpool(o, 3, 2, 1)
+    tap = net.output_nchw(o)
+    net.finalize()
+    x = synth.synth_input(9, (n, 3, h, w))
+    net.set_profiling(True)
+    got = net.forward(x.to(cuda_device))[tap].cpu()
+    torch.cuda.synchronize()
+    variants = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert variants[0] == (952049 if pool else 951049), variants
+
+    def reference(img):
+        xin = (img[:, perm] * torch.tensor(scale).view(1, 3, 1, 1) + torch.tensor(shift).view(1, 3, 1, 1)).half().double()
+        r = F.conv2d(xin, wt.half().double(), None, stride=2, padding=3)        # (the packer folds BN before rounding the weights: compare at 4e-3 as the stem test above)
+        r = F.relu(F.batch_norm(r, bnp[2].double(), bnp[3].double(), bnp[0].double(), bnp[1].double(), training=False, eps=1e-5))
+        return F.max_pool2d(r, 3, 2, 1) if pool else r
+
+    ref = reference(x)
+    assert got.shape == ref.shape
+    assert _rel(got.double(), ref) < 4e-3
+    # borders: first / last pooled rows and columns see the conv's zero padding and the pool's implicit one
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        assert float((got.double()[sl] - ref[sl]).abs().max() / ref.abs().max()) < 4e-3
+    assert torch.equal(got, net.forward(x.to(cuda_device))[tap].cpu())
+    # resized call (bilinear 1/sqrt2 inside the pack kernel): general path, same network
+    net.set_profiling(True)
+    rs = net.forward(x.to(cuda_device), scale=2 ** -0.5)[tap].cpu()
+    torch.cuda.synchronize()
+    assert [v for k, v, ms, fl in net.profile() if k == 1][0] not in (951049, 952049)
+    small = F.interpolate(x, scale_factor=2 ** -0.5, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+    ref_s = reference(small)
+    assert rs.shape == ref_s.shape and _rel(rs.double(), ref_s) < 4e-3
