@@ -643,7 +643,8 @@ bool gdt_conv_stem_eligible(const ConvLaunch& d) {
     if (!k7 && !k3) return false;
     if (d.pad_reflect && (d.H <= 3 || d.W <= 3)) return false;
     if (d.stats && (d.sy != 1 || d.OW % 32 != 0 || d.OH % 16 != 0)) return false;
-    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+    // (pixel indices are ints, element offsets longs: 32 x 3 x 1024 x 1024 -> 2^31 output elements is fine)
+    return (long)d.N * d.OH * d.OW < (1L << 31) && (long)d.N * d.H * d.W < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
 }
 
 int gdt_launch_conv_stem(const ConvLaunch& d, hipStream_t stream) {
@@ -662,7 +663,7 @@ bool gdt_conv_stem_c_eligible(const ConvLaunch& d) {
     if (!k7 && !k3) return false;
     if (d.pad_reflect && (d.H <= 3 || d.W <= 3)) return false;
     if (d.stats && (d.sy != 1 || d.OW % 32 != 0 || d.OH % 16 != 0)) return false;
-    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+    return (long)d.N * d.OH * d.OW * 64 < (1L << 32) && (long)d.N * d.H * d.W < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;      // (unsigned 32-bit element offsets in the fp32 epilogue)
 }
 
 int gdt_launch_conv_stem_c(const ConvLaunch& d, hipStream_t stream) {
@@ -678,7 +679,7 @@ bool gdt_conv_stem_pair_eligible(const ConvLaunch& d) {
     if (mode == 0 || !d.w_frag || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm || d.pool2 || d.stats || d.pad_reflect) return false;
     if (d.ntaps != 49 || d.TW != 7 || d.dy0 != -3 || d.dx0 != -3 || d.sy != 2 || d.sx != 2 || d.dys != 1 || d.dxs != 1) return false;
     if (d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0 || d.H < 8 || d.W < 8) return false;
-    return (long)d.N * d.OH * d.OW * 64 < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
+    return (long)d.N * d.OH * d.OW < (1L << 31) && (long)d.H * d.W < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
 }
 
 int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream) {
