@@ -489,6 +489,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
             if (len >= 14 && memcmp(f + r.pos, "Adobe", 5) == 0) { adobe = true; adobe_transform = f[r.pos + 11]; }
         } else if (m == 0xDA) {
             if (!have_frame) return fail("scan before the frame header");
+            if (len < 6 + 2) return fail("bad scan header");
             const int ns = r.u8();
             if (ns != info->ncomp) return fail("only single-scan (interleaved) files are decoded on the device");
             if (len != 6 + 2 * ns) return fail("bad scan header");

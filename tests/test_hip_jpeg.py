@@ -146,3 +146,26 @@ def test_golden_files():
         got = jpeg.decode_many(blobs, "cuda:0", sequential=sequential)
         for n, t in zip(g["names"], got):
             assert np.array_equal(t.cpu().numpy(), g["rgb_" + str(n)]), (str(n), sequential)
+
+
+def test_corrupted_entropy_data_decodes_to_something_without_harm():
+    """damaged scans (random bytes overwritten, none of them 0xFF so the markers stay where they are): the decoder must finish, keep to its
+    buffers and leave the intact files of the same call byte-exact -- what the damaged ones look like is undefined (Pillow's output for
+    them depends on its own error recovery and is not compared)"""
+    rng = np.random.RandomState(5)
+    good = [_encode(_picture(200, 150, 1), quality=85, subsampling=2), _encode(_picture(97, 61, 2), quality=70, subsampling=0)]
+    bad = []
+    for blob in (good[0], good[1], _encode(_picture(160, 120, 3), quality=90, subsampling=1, restart_marker_rows=2)):
+        b = bytearray(blob)
+        start = blob.index(b"\xff\xda") + 14
+        for _ in range(40):
+            k = rng.randint(start, len(b) - 2)
+            if b[k] != 0xFF and b[k - 1] != 0xFF:
+                b[k] = rng.randint(0, 255)
+        bad.append(bytes(b))
+    out = jpeg.decode_many([good[0]] + bad + [good[1]], "cuda:0")
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), _reference(good[0])) and np.array_equal(out[-1].cpu().numpy(), _reference(good[1]))
+    for t, blob in zip(out[1:-1], bad):
+        p = jpeg.parse(blob)
+        assert tuple(t.shape) == (p.info.height, p.info.width, 3)

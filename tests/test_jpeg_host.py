@@ -100,3 +100,32 @@ def test_golden_files_parse_and_pillow_still_reproduces_them():
         assert p.size == (want.shape[1], want.shape[0])
         with Image.open(io.BytesIO(blob)) as img:
             assert np.array_equal(np.asarray(img.convert("RGB")), want), name
+
+
+def test_parser_survives_truncated_and_corrupted_files():
+    """the host parser reads untrusted bytes: every truncation and a few thousand random corruptions of valid files must come back as a
+    clean ValueError or as a consistent info (whose scan extraction then stays inside the buffer it was sized for) -- never a crash"""
+    rng = np.random.RandomState(3)
+    arr = rng.randint(0, 256, (40, 56, 3), dtype=np.uint8)
+    files = [_encode(arr, quality=85, subsampling=2), _encode(arr, quality=60, subsampling=0, optimize=True, restart_marker_blocks=2),
+             _encode(arr[:, :, 0], quality=75)]
+    accepted = refused = 0
+    for blob in files:
+        header = blob.index(b"\xff\xda") + 16
+        cases = [blob[:k] for k in range(0, len(blob), 1 if len(blob) < 1200 else 3)]
+        for _ in range(1500):
+            b = bytearray(blob)
+            for _ in range(rng.randint(1, 4)):
+                b[rng.randint(2, header)] = rng.randint(0, 256)
+            cases.append(bytes(b))
+        for c in cases:
+            try:
+                p = jpeg.parse(c)
+            except ValueError:
+                refused += 1
+                continue
+            accepted += 1
+            assert 0 < p.info.width <= 65535 and 0 < p.info.height <= 65535 and p.info.nsegments >= 1
+            data, seg = _scan(p)
+            assert len(data) == p.info.scan_capacity and seg[-1] + 16 <= p.info.scan_capacity and all(a <= b2 for a, b2 in zip(seg, seg[1:]))
+    assert accepted > 50 and refused > 1000
