@@ -14,6 +14,7 @@ database indices per query column, best first.  On a HIP device the descriptors 
 (gandtr_amd/retrieval.py: split-fp16 GEMM + segmented radix sort); on the CPU the reference's two numpy lines run as they are.
 """
 import copy
+import os
 import time
 
 import numpy as np
@@ -102,9 +103,21 @@ def _rank_images(params, data):
     network = load_network(copy.deepcopy(params["network"]), device).eval()
     images = data[0]
     qimages = data[1] if len(data) > 1 and data[1] is not None else None
+
+    def describe(items):
+        # image FILES (paths or contents), as the reference's datasets hold them: decoded, resized to the dataset's image size (cirtorch's test
+        # size 1024 unless data[2] = {"image_size": s} says otherwise) and normalised with the network's own mean / std on the device
+        if len(items) and isinstance(items[0], (str, bytes, bytearray, os.PathLike)):
+            opts = data[2] if len(data) > 2 and data[2] else {}
+            mean_std = network.network_params.runtime.get("data", {}).get("mean_std")
+            if mean_std is None:
+                raise ValueError("image files need runtime.data.mean_std in the network parameters (the transform the reference builds its dataset with)")
+            return extract_vectors_from_files(network, list(items), opts.get("image_size", 1024), mean_std, device, host_loader=opts.get("host_loader"))
+        return extract_vectors(network, items, device)
+
     t0 = time.time()
-    vecs = extract_vectors(network, images, device)
-    qvecs = vecs.clone() if qimages is None else extract_vectors(network, qimages, device)
+    vecs = describe(images)
+    qvecs = vecs.clone() if qimages is None else describe(qimages)
     t1 = time.time()
     scores, ranks = rank(vecs, qvecs)
     t2 = time.time()
@@ -115,7 +128,8 @@ def _rank_images(params, data):
 
 def rank_images(params, data):
     """Stage ``gandtr_amd.stages.validate.rank_images`` (this build's own name: the reference has no such stage).
-    ``params = {"network": ...}``; ``data[0]`` database images, ``data[1]`` query images (omitted: the database queries itself).
+    ``params = {"network": ...}``; ``data[0]`` database images, ``data[1]`` query images (omitted: the database queries itself); images are
+    tensors, or image FILES (paths / file contents: decoded, resized and normalised on the device, ``data[2] = {"image_size": s}`` optional).
     Returns ``(metadata, ranks, scores)`` -- two output columns after the metadata, the general stage ABI
     (mdir/examples/perform_scenario.py:129)."""
     assert params.keys() == {"network"}, params.keys()

@@ -403,3 +403,37 @@ def test_extract_vectors_from_files_equals_the_pillow_pipeline(cuda_device, tmp_
     ref = extract_vectors(net, want, cuda_device)
     assert got.shape == ref.shape == (512, 7)
     assert float((got - ref).abs().max()) < 5e-5 and float(torch.nn.functional.cosine_similarity(got.t(), ref.t(), dim=1).min()) > 0.999999
+
+
+def test_rank_images_on_jpeg_files(cuda_device, tmp_path):
+    """the retrieval stage on image FILES, as the reference's datasets hold them: paths and in-memory file contents go through the device
+    decoder + resize + normalise (extract_vectors_from_files); a query that is a re-encoded copy of a database image ranks it first"""
+    import copy
+    import io
+    from PIL import Image
+    from gandtr_amd.stages.validate import rank_images
+    import gandtr_amd.learning as L
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    emb = {"type": "SingleNetwork",
+           "model": {"architecture": "cirnet", "cir_architecture": "vgg16", "local_whitening": False, "pooling": "gem",
+                     "pretrained": False, "regional": False, "whitening": False},
+           "initialize": False, "path": None,
+           "runtime": {"wrappers": "cirfaketuplebatch", "data": {"transforms": "pil2np | totensor | normalize", "mean_std": [mean, std]}}}
+    net = L.load_network(copy.deepcopy(emb), "cpu")
+    net.model.load_state_dict(synth.vgg16_state(0))
+    torch.save(net.state_dict()["net"], tmp_path / "vgg.pth")
+    params = {"network": {"path": str(tmp_path / "vgg.pth"), "runtime": copy.deepcopy(emb["runtime"])}}
+    rng = np.random.RandomState(1)
+    paths, pictures = [], []
+    for i in range(6):
+        h, w = (180, 240) if i % 2 else (240, 180)
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([128 + 90 * np.sin(xx / (6.0 + 2 * i + c)) * np.cos(yy / (5.0 + i)) + rng.normal(0, 10, (h, w)) for c in range(3)], -1)
+        pictures.append(Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8)))
+        paths.append(str(tmp_path / ("db%d.jpg" % i)))
+        pictures[-1].save(paths[-1], "JPEG", quality=90, subsampling=i % 3)
+    buf = io.BytesIO()
+    pictures[4].save(buf, "JPEG", quality=60)                       # the query: image 4 again, other quality (bytes, not a path)
+    meta, ranks, scores = rank_images(params, (paths, [buf.getvalue()], {"image_size": 160}))
+    assert ranks.shape == (6, 1) and ranks[0, 0] == 4 and scores[4, 0] > 0.97
+    assert meta["eval"]["database"] == 6 and meta["eval"]["queries"] == 1
