@@ -84,6 +84,9 @@ SIGNATURES = {
                                            c_void_p]),
     "gdt_jpeg_parse": (c_int, [c_void_p, c_size_t, POINTER(JpegInfo)]),
     "gdt_jpeg_extract_scan": (c_int, [c_void_p, c_size_t, POINTER(JpegInfo), c_void_p, POINTER(ctypes.c_uint)]),
+    "gdt_jpeg_parse_batch": (c_int, [POINTER(c_void_p), POINTER(c_size_t), c_int, POINTER(JpegInfo), _IP, c_int]),
+    "gdt_jpeg_extract_scan_batch": (c_int, [POINTER(c_void_p), POINTER(c_size_t), POINTER(JpegInfo), c_int, c_void_p, POINTER(c_size_t),
+                                            POINTER(ctypes.c_uint), POINTER(c_size_t), c_int]),
     "gdt_jpeg_decode_workspace_bytes": (c_int, [POINTER(JpegItem), c_int, POINTER(c_size_t)]),
     "gdt_jpeg_decode_u8_batch": (c_int, [POINTER(JpegItem), c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gdt_whiten_learn_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),

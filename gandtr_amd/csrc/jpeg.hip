@@ -30,7 +30,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gandtr_hip.h"
@@ -683,6 +685,19 @@ int run_decode(const gdt_jpeg_item* items, int n, int mode, const Plan& p, char*
     return GDT_OK;
 }
 
+// the two host steps for a LIST of files on a few threads (they are independent per file and memory-bound; one call instead of 2n also spares a
+// scripting host its per-call overhead)
+template <typename F>
+void for_each_file(int n, int threads, F&& fn) {
+    threads = std::max(1, std::min(threads, std::min(n, 16)));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+    for (auto& th : pool) th.join();
+}
+
 }  // namespace
 
 extern "C" {
@@ -700,6 +715,23 @@ int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jp
                 "jpeg: the file does not match the info");
     seg_off[info->nsegments] = (unsigned int)w.data_bytes;
     memset(dst + w.data_bytes, 0, info->scan_capacity - w.data_bytes);
+    return GDT_OK;
+}
+
+int gdt_jpeg_parse_batch(const unsigned char* const* files, const size_t* nbytes, int n, gdt_jpeg_info* infos, int* status, int threads) {
+    GDT_REQUIRE(files != nullptr && nbytes != nullptr && infos != nullptr && status != nullptr && n >= 0, "jpeg: null argument");
+    for_each_file(n, threads, [&](int i) { status[i] = files[i] ? parse_impl(files[i], nbytes[i], &infos[i]) : GDT_ERR_INVALID; });
+    return GDT_OK;
+}
+
+int gdt_jpeg_extract_scan_batch(const unsigned char* const* files, const size_t* nbytes, const gdt_jpeg_info* infos, int n, unsigned char* dst,
+                                const size_t* dst_off, unsigned int* seg_off, const size_t* seg_index, int threads) {
+    GDT_REQUIRE(files != nullptr && nbytes != nullptr && infos != nullptr && dst != nullptr && dst_off != nullptr && seg_off != nullptr && seg_index != nullptr && n >= 0,
+                "jpeg: null argument");
+    std::vector<int> rc(n, GDT_OK);
+    for_each_file(n, threads, [&](int i) { rc[i] = gdt_jpeg_extract_scan(files[i], nbytes[i], &infos[i], dst + dst_off[i], seg_off + seg_index[i]); });
+    for (int i = 0; i < n; ++i)
+        if (rc[i] != GDT_OK) { gdt_set_error("jpeg: file " + std::to_string(i) + " of the list does not match its info"); return rc[i]; }
     return GDT_OK;
 }
 

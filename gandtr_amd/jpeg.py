@@ -9,6 +9,7 @@ headers and strips the byte stuffing from the entropy-coded segment while stagin
 Baseline files only (8-bit, Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0).  ``parse`` raises ValueError for
 anything else, with the reason; ``load_many`` passes that on unless the caller supplies its own loader for such files."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,37 @@ def parse(data):
     return Parsed(data)
 
 
+_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+
+
+def _ptr_array(blobs):
+    keep = [ctypes.c_char_p(b) for b in blobs]                # (borrowed pointers into the bytes objects, kept alive by the caller's list)
+    return (ctypes.c_void_p * len(blobs))(*[ctypes.cast(k, ctypes.c_void_p).value for k in keep]), keep
+
+
+def parse_many(blobs):
+    """``[Parsed(b) for b in blobs]`` in ONE library call on a few host threads (gdt_jpeg_parse_batch); the first refused file raises the
+    ValueError ``parse`` would raise for it."""
+    blobs = [bytes(b) for b in blobs]
+    n = len(blobs)
+    if n == 0:
+        return []
+    infos = (_hip.JpegInfo * n)()
+    status = (ctypes.c_int * n)()
+    files, keep = _ptr_array(blobs)
+    sizes = (ctypes.c_size_t * n)(*[len(b) for b in blobs])
+    _hip.check(_hip.load().gdt_jpeg_parse_batch(files, sizes, n, infos, status, _THREADS))
+    out = []
+    for i, b in enumerate(blobs):
+        if status[i] != _hip.GDT_OK:
+            Parsed(b)                                          # raises with the reason
+            raise ValueError("JPEG file %d of the list was refused" % i)
+        p = Parsed.__new__(Parsed)
+        p.data, p.info = b, infos[i]
+        out.append(p)
+    return out
+
+
 _stage = None
 
 
@@ -60,20 +92,26 @@ def decode_many(blobs, device=None, sequential=False):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if device.type != "cuda":
         raise ValueError("JPEG decoding runs on a HIP device only (there is no CPU path)")
-    parsed = [b if isinstance(b, Parsed) else Parsed(b) for b in blobs]
+    raw = [i for i, b in enumerate(blobs) if not isinstance(b, Parsed)]
+    parsed = list(blobs)
+    for i, p in zip(raw, parse_many([blobs[i] for i in raw])):
+        parsed[i] = p
+    n = len(parsed)
     # staging: every image's un-stuffed scan at a 16-byte aligned offset of ONE pinned buffer -> one upload
-    offs, total = [], 0
+    offs, total, seg_index, nseg = [], 0, [], 0
     for p in parsed:
         offs.append(total)
         total += (int(p.info.scan_capacity) + 15) // 16 * 16
+        seg_index.append(nseg)
+        nseg += p.info.nsegments + 1
     torch.cuda.current_stream(device).synchronize()      # (an upload from the staging buffer may still be in flight)
     stage = _staging(total)
-    base = stage.data_ptr()
-    seg_tables = []
-    for p, off in zip(parsed, offs):
-        seg = (ctypes.c_uint * (p.info.nsegments + 1))()
-        _hip.check(lib.gdt_jpeg_extract_scan(p.data, len(p.data), ctypes.byref(p.info), ctypes.c_void_p(base + off), seg))
-        seg_tables.append(seg)
+    seg_all = (ctypes.c_uint * nseg)()
+    infos = (_hip.JpegInfo * n)(*[p.info for p in parsed])
+    files, keep = _ptr_array([p.data for p in parsed])
+    _hip.check(lib.gdt_jpeg_extract_scan_batch(files, (ctypes.c_size_t * n)(*[len(p.data) for p in parsed]), infos, n, stage.data_ptr(),
+                                               (ctypes.c_size_t * n)(*offs), seg_all, (ctypes.c_size_t * n)(*seg_index), _THREADS))
+    seg_base = ctypes.addressof(seg_all)
     with torch.cuda.device(device):
         scans = stage.to(device, non_blocking=True)
         out_offs, out_total = [], 0
@@ -83,9 +121,9 @@ def decode_many(blobs, device=None, sequential=False):
         out = torch.empty(out_total, dtype=torch.uint8, device=device)
         items = (_hip.JpegItem * len(parsed))()
         for i, (p, off, oo) in enumerate(zip(parsed, offs, out_offs)):
-            items[i].info = ctypes.pointer(p.info)
+            items[i].info = ctypes.pointer(infos[i])
             items[i].scan = scans.data_ptr() + off
-            items[i].seg_off = ctypes.cast(seg_tables[i], ctypes.POINTER(ctypes.c_uint))
+            items[i].seg_off = ctypes.cast(seg_base + 4 * seg_index[i], ctypes.POINTER(ctypes.c_uint))
             items[i].dst_hwc = out.data_ptr() + oo
         nbytes = ctypes.c_size_t()
         _hip.check(lib.gdt_jpeg_decode_workspace_bytes(items, len(parsed), ctypes.byref(nbytes)))

@@ -255,6 +255,12 @@ typedef struct gdt_jpeg_info {
 } gdt_jpeg_info;
 int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info);
 int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off);
+/* the same two steps for a list of files on `threads` host threads (1 = in the calling thread): status[i] = what gdt_jpeg_parse would return for file i
+ * (call it on that file for the message); file i's scan goes to dst + dst_off[i] (info.scan_capacity bytes) and its nsegments + 1 offsets to
+ * seg_off + seg_index[i]. */
+int gdt_jpeg_parse_batch(const unsigned char* const* files, const size_t* nbytes, int n, gdt_jpeg_info* infos, int* status, int threads);
+int gdt_jpeg_extract_scan_batch(const unsigned char* const* files, const size_t* nbytes, const gdt_jpeg_info* infos, int n, unsigned char* dst,
+                                const size_t* dst_off, unsigned int* seg_off, const size_t* seg_index, int threads);
 typedef struct gdt_jpeg_item {
     const gdt_jpeg_info* info;     /* host */
     const unsigned char* scan;     /* device: the bytes gdt_jpeg_extract_scan produced (scan_capacity of them) */

@@ -66,7 +66,7 @@ def run(n=64, w=1024, h=768, quality=90, subsampling=2):
             "device_single_file_ms": round(t_one * 1e3, 3), "one_thread_per_interval_decoder_files_per_s": round(8 / t_seq, 1),
             "pillow_host_1_thread_files_per_s": round(n / t_pil, 1), "speedup_vs_1_host_thread": round(t_pil / t_dev, 1),
             "files_to_normalised_362_tensor_per_s": round(n / t_ing, 1), "pillow_pipeline_1_thread_files_per_s": round(n / t_pil_ing, 1),
-            "note": "device figures include header parsing, un-stuffing into the pinned staging buffer and the upload (host, one thread)"}
+            "note": "device figures include header parsing + un-stuffing into the pinned staging buffer (host, one library call each, up to 8 threads) and the upload"}
 
 
 if __name__ == "__main__":
