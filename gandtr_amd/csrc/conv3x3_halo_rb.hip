@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
     constexpr int HW_ = CT ? 17 : HALO_W;                               // halo width / height
     constexpr int HROWS = HW_ * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;   // 324 / 328, or 289 / 296
-    constexpr int NTAP = CT ? 4 : 9, RPS = CT ? 2 : 1;                  // steps per chunk, staging rounds per step
+    constexpr int NTAP = CT ? 4 : 9, RPS = (CT || NT < 512) ? 2 : 1;    // steps per chunk, staging rounds per step (four-wave form: half the loader threads)
     constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
     static_assert(NR <= (NTAP - 1) * RPS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the steps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -458,7 +458,10 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
 // are at least two channel chunks (the next tile's table is staged one chunk ahead).
 bool gdt_conv_halo_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_RB"); return e ? atoi(e) : 1; }();   // 0 off
-    if (mode == 0 || !d.w_frag || d.CoutPad % 256 != 0) return false;
+    // 128 output channels (VGG16 conv2_x, HED): the four-wave form, 2 x 2 waves of the same 128 x 64 wave tile (plain input only)
+    static const int narrow = [] { const char* e = getenv("GDT_CONV_RB128"); return e ? atoi(e) : 1; }();
+    const bool n128 = narrow && d.CoutPad == 128 && !d.in_norm && !d.in_res && !d.in_out && !d.stats;
+    if (mode == 0 || !d.w_frag || (d.CoutPad % 256 != 0 && !n128)) return false;
     if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;    // 32-bit element offsets
     return gdt_conv_halo_eligible(d);
@@ -468,6 +471,7 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
+    if (d.CoutPad == 128) return launch_rb<128, 2, 2, 0>(d, stream);
     if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
