@@ -33,7 +33,7 @@ constexpr int HALO_ROWS = (PH + 2) * HALO_W;               // 324
 constexpr int HALO_ROWS_PAD = (HALO_ROWS + 7) / 8 * 8;     // 328
 constexpr int A_BYTES = HALO_ROWS_PAD * ROWB;
 constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
-constexpr int BM = PH * 16;
+constexpr int BM = PH * 16; static_assert(BM == 256, "16 x 16 patches at file scope");
 
 constexpr int C_OFF = 2 * A_BYTES + NORM_BYTES;            // epilogue transpose patches (one per wave), disjoint from the halo stages
 
@@ -60,8 +60,12 @@ __device__ __forceinline__ unsigned norm_res_pair(unsigned raw, unsigned res, fl
     return o;
 }
 
-template <int BN>
-constexpr size_t rb_lds_bytes() { return (size_t)C_OFF + (size_t)8 * 32 * (BN / 4 + 8) * 2; }      // + eight wave-private transpose patches
+// PHT = 16: two halo stages, the (scale, shift) tables, eight wave-private transpose patches.  PHT = 32 (tall 16 x 32 patches, 64-channel layers): the two
+// 77 KB stages fill the LDS; the patches alias the stage the tile has just finished with (one more workgroup barrier per tile)
+template <int BN, int PHT = 16>
+constexpr size_t rb_lds_bytes() {
+    return PHT == 16 ? (size_t)C_OFF + (size_t)8 * 32 * (BN / 4 + 8) * 2 : (size_t)2 * (((PHT + 2) * HALO_W + 7) / 8 * 8) * ROWB;
+}
 
 struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 
@@ -79,15 +83,19 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 // and a wave skips the (shift, phase) blocks that are all zero; the epilogue scatters column blocks to output pixels
 // (2y + py, 2x + px).  MODE 3 (norm + residual, no write-back) exists for this form: y9 = y8 + IN(.) feeds only the first
 // transposed conv.
-template <int BN, int WGM, int WGN, int MODE, bool CT = false>
+template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
+    constexpr int PH = PHT, BM = PHT * 16;                              // (shadow the 16-row constants of the file scope)
+    constexpr bool ALIAS = PHT > 16;                                    // transpose patches inside the consumed halo stage
     constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
     constexpr int HW_ = CT ? 17 : HALO_W;                               // halo width / height
-    constexpr int HROWS = HW_ * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;   // 324 / 328, or 289 / 296
-    constexpr int NTAP = CT ? 4 : 9, RPS = (CT || NT < 512) ? 2 : 1;    // steps per chunk, staging rounds per step (four-wave form: half the loader threads)
+    constexpr int HROWS = (CT ? HW_ : PHT + 2) * HW_, HROWS_PAD = (HROWS + 7) / 8 * 8;   // 324 / 328, 289 / 296 (CT), 612 / 616 (tall patches)
+    constexpr int A_BYTES = PHT == 16 ? HALO_ROWS_PAD * ROWB : HROWS_PAD * ROWB;         // (shadows the file-scope constant)
+    constexpr int NTAP = CT ? 4 : 9;                                    // steps per chunk
     constexpr int NR = (HROWS_PAD + RPR - 1) / RPR;
-    static_assert(NR <= (NTAP - 1) * RPS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the steps of the previous chunk");
+    constexpr int RPS = (NR + NTAP - 2) / (NTAP - 1);                   // staging rounds per step (1 with eight waves, 2 / 3 with four)
+    static_assert(NR <= (NTAP - 1) * RPS && HROWS_PAD * ROWB <= A_BYTES && !(CT && PHT != 16), "halo rounds are spread over the steps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 2 && TM % 2 == 0 && TN >= 1 && WTM == 128, "tile shape (one 128-row statistics record per wave row)");
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         // fixed butterfly -- no cross-wave step (the four waves of a row write disjoint channel ranges of the record).
         if (!(d.dbg & 4)) {
             constexpr int PCP = WTN + 8;                                   // halves per patch row (64 + 8)
-            f16* patch = (f16*)(smem + C_OFF) + wave * (32 * PCP);
+            f16* patch = (f16*)(smem + (ALIAS ? so : C_OFF)) + wave * (32 * PCP);
             const bool relu_now = d.relu && !d.res;
             const bool has_res = d.res != nullptr;
             int fr_e = fr, fh_e = fh, lane_e = lane;            // (opaque copies: keeps the epilogue's addresses out of the
@@ -423,6 +431,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             if (sacc == 12345.678f) d.out[0] = (f16)sacc;
         }
         if (!nxt.valid) break;
+        if (ALIAS) {                     // the patches lie in the stage the next tile stages its second chunk (or its successor's first) into
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         cur = nxt; vb += gridDim.x; slot ^= 1;
         so = A_BYTES - so;
 #pragma unroll
@@ -430,10 +443,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
     }
 }
 
-template <int BN, int WGM, int WGN, int MODE, bool CT = false>
+template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16>
 int launch_rb(const ConvLaunch& d, hipStream_t stream) {
-    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
-    constexpr size_t lds = rb_lds_bytes<BN>();
+    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PHT - 1) / PHT), ntn = d.CoutPad / BN;
+    constexpr size_t lds = rb_lds_bytes<BN, PHT>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     static int cus = 0;
     if (!cus) {
@@ -441,12 +454,12 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     static const int persist = [] { const char* e = getenv("GDT_RB_PERSIST"); return e ? atoi(e) : 1; }();
     const int grid = (vblocks < cus || !persist) ? vblocks : cus * (persist > 1 ? persist : 1) / (persist > 1 ? 2 : 1);
-    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
+    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -460,7 +473,10 @@ bool gdt_conv_halo_rb_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_RB"); return e ? atoi(e) : 1; }();   // 0 off
     // 128 output channels (VGG16 conv2_x, HED): the four-wave form, 2 x 2 waves of the same 128 x 64 wave tile (plain input only)
     static const int narrow = [] { const char* e = getenv("GDT_CONV_RB128"); return e ? atoi(e) : 1; }();
-    const bool n128 = narrow && d.CoutPad == 128 && !d.in_norm && !d.in_res && !d.in_out && !d.stats;
+    const bool plain = !d.in_norm && !d.in_res && !d.in_out && !d.stats;
+    bool n128 = narrow && d.CoutPad == 128 && plain;
+    // 64 output channels (VGG16 conv1_2, HED): 4 x 1 waves on a tall 16 x 32 patch; at most 15 % of the patch rows may hang over the image
+    if (narrow && d.CoutPad == 64 && plain && (double)d.H / ((d.H + 31) / 32 * 32) >= 0.85) n128 = true;
     if (mode == 0 || !d.w_frag || (d.CoutPad % 256 != 0 && !n128)) return false;
     if (d.in_norm && (d.Cin > 256 || d.Cin < 128)) return false;
     if ((long)d.N * d.H * d.W * d.Cin >= (1L << 32) || (long)d.N * d.H * d.W * d.Cout >= (1L << 32)) return false;    // 32-bit element offsets
@@ -472,6 +488,7 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
     d.dbg = dbg;
     if (d.CoutPad == 128) return launch_rb<128, 2, 2, 0>(d, stream);
+    if (d.CoutPad == 64) return launch_rb<64, 4, 1, 0, false, 32>(d, stream);
     if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);

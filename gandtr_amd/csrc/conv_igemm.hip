@@ -334,7 +334,7 @@ int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
         if (bn == 64) { *variant = 128064; return launch_cfg<128, 64, 2, 2, true>(d, stream); }
         *variant = 128032; return launch_cfg<128, 32, 4, 1, true>(d, stream);
     }
-    if (gdt_conv_halo_rb_eligible(d)) { *variant = 910000 + (d.CoutPad == 128 ? 128 : 256); return gdt_launch_conv_halo_rb(d, stream); }
+    if (gdt_conv_halo_rb_eligible(d)) { *variant = 910000 + (d.CoutPad < 256 ? d.CoutPad : 256); return gdt_launch_conv_halo_rb(d, stream); }
     if (gdt_conv_halo_eligible(d)) { *variant = 900000 + (d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64)); return gdt_launch_conv_halo(d, stream); }
     if (d.pad_reflect) {
         const int pady = d.dy0 < 0 ? -d.dy0 : 0, padx = d.dx0 < 0 ? -d.dx0 : 0;
