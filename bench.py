@@ -134,8 +134,8 @@ def kernel_name(variant):
         return "conv_stem_kernel<%d taps>[f16c]" % (variant - 955000)
     if variant == 952049:
         return "conv_stem_pair_pool_kernel"                # ResNet stem from the fp32 image + MaxPool2d(3, 2, 1)
-    if variant == 951049:
-        return "conv_stem_pair_kernel"
+    if 951000 <= variant < 952000:
+        return "conv_stem_pair_kernel<%d taps>" % (variant - 951000)   # first conv straight from the fp32 NCHW image
     if variant >= 950000:
         return "conv_stem_kernel<%d taps>" % (variant - 950000)
     if variant == 946128:

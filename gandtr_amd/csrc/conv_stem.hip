@@ -293,16 +293,25 @@ int launch_stem(const ConvLaunch& d, hipStream_t stream) {
 //     expression as the pack kernel: identical bits), rounded to fp16 and written twice (as the low half of its own word and the high half of
 //     its left neighbour's); the loads of the NEXT tile are issued before the MFMAs of this one and land under them and the epilogue.
 // Everything else (swapped operands, wave-private transpose patch, 128-byte line stores) is the fp16 stem above.
-constexpr int SP_HH = 21, SP_HW = 70, SP_PIX = SP_HH * SP_HW;                 // halo of an 8 x 32 output tile (+ one column for the pair words)
-constexpr int SP_ROUNDS = (SP_PIX + NT - 1) / NT;                              // 6
-constexpr int SP_NKS = 14;
-constexpr int SP_WBYTES = SP_NKS * 2 * 1024, SP_HBYTES = (SP_PIX * 16 + 1023) / 1024 * 1024;
-constexpr int SP_LDS = SP_WBYTES + SP_HBYTES + NWAVE * PATCH_BYTES;
 
 struct StemPairArgs { const float* x; int C; int perm[4]; float scale[4], shift[4]; };
 
+// <7, 2>: the ResNet stem.  <3, 1>: VGG16 conv1_1 / the HED trunk's first conv (16 x 32 output tiles; a kernel row is ONE k-step: taps 0, 1 | 2, -).
+template <int KS, int S>
+struct PairCfg {
+    static constexpr int RPW = S == 1 ? 4 : 2, TH = RPW * NWAVE;
+    static constexpr int HH = (TH - 1) * S + KS, HW = 31 * S + KS + 1, PIX = HH * HW;        // (+ one column for the pair words)
+    static constexpr int ROUNDS = (PIX + NT - 1) / NT;
+    static constexpr int HPR = (KS + 3) / 4, NKS = KS * HPR;                                 // k-steps per kernel row, in all
+    static constexpr int WBYTES = NKS * 2 * 1024, HBYTES = (PIX * 16 + 1023) / 1024 * 1024;
+    static constexpr int LDS = WBYTES + HBYTES + NWAVE * PATCH_BYTES;
+};
+
+template <int KS, int S>
 __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch d, const StemPairArgs a, const int ntiles) {
-    constexpr int RPW = 2, TH = RPW * NWAVE, HW = SP_HW;
+    using C = PairCfg<KS, S>;
+    constexpr int RPW = C::RPW, TH = C::TH, HW = C::HW, PAD = KS / 2;
+    constexpr int SP_ROUNDS = C::ROUNDS, SP_PIX = C::PIX, SP_NKS = C::NKS, SP_WBYTES = C::WBYTES, SP_HBYTES = C::HBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wlds = smem;
     char* hbuf = smem + SP_WBYTES;
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
         for (int j = 0; j < SP_ROUNDS; ++j) {
             const int p = min(j * NT + tid, SP_PIX - 1);
             const int hy = p / HW, hx = p - hy * HW;
-            const int iy = y0 * 2 - 3 + hy, ix = x0 * 2 - 3 + hx;
+            const int iy = y0 * S - PAD + hy, ix = x0 * S - PAD + hx;
             const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
             const unsigned off = (unsigned)(min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1));
             pin = j == 0 ? (unsigned)inb : pin | ((unsigned)inb << j);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
             }
         }
     };
-    const int a_lane = ((wave * RPW * 2) * HW + fr * 2 + 2 * fh) * 16;
+    const int a_lane = ((wave * RPW * S) * HW + fr * S + 2 * fh) * 16;
     float4 bvs[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -379,12 +388,12 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         {
-            constexpr int PF = 3;
+            constexpr int PF = SP_NKS >= 3 ? 3 : SP_NKS;
             f16x8 af[PF][RPW], bf[PF][2];
             auto frags = [&](int ks, f16x8 (&av)[RPW], f16x8 (&bv)[2]) {
-                const int ty = ks >> 1, h = ks & 1;
+                const int ty = ks / C::HPR, h = ks % C::HPR;
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) av[i] = *(const f16x8*)(hbuf + a_lane + ((i * 2 + ty) * HW + 4 * h) * 16);
+                for (int i = 0; i < RPW; ++i) av[i] = *(const f16x8*)(hbuf + a_lane + ((i * S + ty) * HW + 4 * h) * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bv[j] = *(const f16x8*)(wlds + ((ks * 2 + j) * 64 + lane) * 16);
             };
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_pair_kernel(const ConvLaunch 
 #ifndef GDT_STEM_POOL_EARLY_PREFETCH
 #define GDT_STEM_POOL_EARLY_PREFETCH 0      // 1: next tile's loads before the MFMAs (14 spilled registers; measured 0.58 vs 0.55 ms)
 #endif
+constexpr int SP_HW = PairCfg<7, 2>::HW, SP_NKS = PairCfg<7, 2>::NKS, SP_WBYTES = PairCfg<7, 2>::WBYTES;
 constexpr int SQ_HH = 37, SQ_PIX = SQ_HH * SP_HW, SQ_ROUNDS = (SQ_PIX + NT - 1) / NT;      // halo of 16 x 32 conv outputs; 11 loader rounds
 constexpr int SQ_HBYTES = (SQ_PIX * 16 + 1023) / 1024 * 1024;
 constexpr int SQ_LDS = SP_WBYTES + SQ_HBYTES + 256;                                          // + the bias vector
@@ -677,30 +687,38 @@ int gdt_launch_conv_stem_c(const ConvLaunch& d, hipStream_t stream) {
 bool gdt_conv_stem_pair_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_STEM_PAIR"); return e ? atoi(e) : 1; }();
     if (mode == 0 || !d.w_frag || d.Cout != 64 || d.CoutPad != 64 || d.out_f32 || !d.out || d.res || d.in_norm || d.pool2 || d.stats || d.pad_reflect) return false;
-    if (d.ntaps != 49 || d.TW != 7 || d.dy0 != -3 || d.dx0 != -3 || d.sy != 2 || d.sx != 2 || d.dys != 1 || d.dxs != 1) return false;
+    const bool k7s2 = d.ntaps == 49 && d.TW == 7 && d.dy0 == -3 && d.dx0 == -3 && d.sy == 2 && d.sx == 2;
+    const bool k3s1 = d.ntaps == 9 && d.TW == 3 && d.dy0 == -1 && d.dx0 == -1 && d.sy == 1 && d.sx == 1;
+    if ((!k7s2 && !k3s1) || d.dys != 1 || d.dxs != 1) return false;
     if (d.osy != 1 || d.osx != 1 || d.ooy != 0 || d.oox != 0 || d.H < 8 || d.W < 8) return false;
     return (long)d.N * d.OH * d.OW < (1L << 31) && (long)d.H * d.W < (1L << 31) && (long)d.N * d.OH * d.OW >= 65536;
 }
 
-int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream) {
-    GDT_REQUIRE(x != nullptr && C >= 1 && C <= 3, "stem: 1..3 image channels");
-    static_assert(2 * SP_LDS <= 160 * 1024, "two workgroups per CU");
+template <int KS, int S>
+static int launch_stem_pair(const ConvLaunch& d, const StemPairArgs& a, hipStream_t stream) {
+    using C = PairCfg<KS, S>;
+    static_assert(2 * C::LDS <= 160 * 1024, "two workgroups per CU");
     static int cus = 0;
     if (!cus) {
         int dev = 0;
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
     }
+    const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + C::TH - 1) / C::TH);
+    const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((conv_stem_pair_kernel<KS, S>), dim3(grid), dim3(NT), C::LDS, stream, d, a, ntiles);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
+}
+
+int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, hipStream_t stream) {
+    GDT_REQUIRE(x != nullptr && C >= 1 && C <= 3, "stem: 1..3 image channels");
     StemPairArgs a;
     a.x = x; a.C = C;
     for (int c = 0; c < 4; ++c) { a.perm[c] = c < C ? perm[c] : 0; a.scale[c] = c < C ? scale[c] : 0.f; a.shift[c] = c < C ? shift[c] : 0.f; }
-    const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + 7) / 8);
-    const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
-    hipLaunchKernelGGL(conv_stem_pair_kernel, dim3(grid), dim3(NT), SP_LDS, stream, d, a, ntiles);
-    GDT_CHECK_HIP(hipGetLastError());
-    return GDT_OK;
+    return d.ntaps == 9 ? launch_stem_pair<3, 1>(d, a, stream) : launch_stem_pair<7, 2>(d, a, stream);
 }
 
 // ... with the following MaxPool2d(3, 2, 1) fused: d.out is the POOLED tensor [N][PH][PW][64]

@@ -857,16 +857,18 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                         }
             ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
             ph.has_frag = true;
-            if (cd.kh == 7 && cd.kw == 7 && cd.stride == 2 && cd.pad == 3 && !cd.pad_reflect && cd.cin <= 3) {
-                // conv_stem_pair_kernel: k-step ks = ty * 2 + h covers taps tx = 4h .. 4h + 3 of kernel row ty; lane (fh, fr) element e = tap 4h + 2fh + (e >> 2),
-                // channel slot e & 3 (3 real channels; tap 7 does not exist: zero)
-                std::vector<f16> pp((size_t)14 * 2 * 64 * 8, (f16)0.f);
-                for (int ks = 0; ks < 14; ++ks)
+            const bool k7s2 = cd.kh == 7 && cd.kw == 7 && cd.stride == 2 && cd.pad == 3, k3s1 = cd.kh == 3 && cd.kw == 3 && cd.stride == 1 && cd.pad == 1;
+            if ((k7s2 || k3s1) && !cd.pad_reflect && cd.cin <= 3) {
+                // conv_stem_pair_kernel: a kernel row is HPR k-steps of four taps; k-step ks = ty * HPR + h covers taps tx = 4h .. 4h + 3 of row ty; lane (fh, fr)
+                // element e = tap 4h + 2fh + (e >> 2), channel slot e & 3 (3 real channels; taps past the kernel do not exist: zero)
+                const int KS = cd.kh, HPR = (KS + 3) / 4, NKS = KS * HPR;
+                std::vector<f16> pp((size_t)NKS * 2 * 64 * 8, (f16)0.f);
+                for (int ks = 0; ks < NKS; ++ks)
                     for (int j = 0; j < 2; ++j)
                         for (int ln = 0; ln < 64; ++ln)
                             for (int e = 0; e < 8; ++e) {
-                                const int ty = ks >> 1, tx = 4 * (ks & 1) + 2 * (ln >> 5) + (e >> 2), ch = e & 3;
-                                if (tx < 7 && ch < cd.cin) pp[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = pk[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + (ty * 7 + tx) * 8 + ch];
+                                const int ty = ks / HPR, tx = 4 * (ks % HPR) + 2 * (ln >> 5) + (e >> 2), ch = e & 3;
+                                if (tx < KS && ch < cd.cin) pp[(((size_t)ks * 2 + j) * 64 + ln) * 8 + e] = pk[(size_t)(j * 32 + (ln & 31)) * ph.Kpad + (ty * KS + tx) * 8 + ch];
                             }
                 ph.w_pair_off = net->blob_append(pp.data(), pp.size() * sizeof(f16));
                 ph.has_pair = true;
@@ -1324,7 +1326,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.out = tptr(o.out);
                         rc = gdt_launch_conv_stem_pair(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, st);
                     }
-                    if (net->profiling) net->last_variant[stp.op] = stp.pool_into >= 0 ? 952049 : 951049;
+                    if (net->profiling) net->last_variant[stp.op] = stp.pool_into >= 0 ? 952049 : 951000 + o.phases[0].ntaps;
                     break;
                 }
                 if (stp.kcat) {                // expand conv + its projection shortcut as one K-concatenated 1x1 GEMM (conv1x1_rb.hip)

@@ -351,3 +351,26 @@ def test_resnet_stem_from_the_fp32_image(cuda_device, pool, n, h, w):
     small = F.interpolate(x, scale_factor=2 ** -0.5, mode="bilinear", align_corners=False, recompute_scale_factor=False)
     ref_s = reference(small)
     assert rs.shape == ref_s.shape and _rel(rs.double(), ref_s) < 4e-3
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 270, 310), (2, 256, 512)])
+def test_vgg_first_conv_from_the_fp32_image(cuda_device, n, h, w):
+    """conv_stem_pair_kernel<3, 1>: Conv2d(3, 64, 3, pad 1) + ReLU (VGG16 conv1_1, the HED trunk's first conv) read straight from the caller's
+    fp32 NCHW image with the wrappers' BGR permutation and mean / std folded in; ragged 16 x 32 tiles; against fp64."""
+    from gandtr_amd.engine import HipNet
+    perm, scale, shift = [2, 1, 0], [255.0, 255.0, 255.0], [-104.0, -117.0, -123.0]
+    net = HipNet(cuda_device)
+    t = net.input(3, perm=perm, scale=scale, shift=shift)
+    wt, b = synth._normal(0, "wv", (64, 3, 3, 3), 0.004), synth._normal(0, "bv", (64,), 0.2)
+    tap = net.output_nchw(net.conv(t, wt, b, pad=1, relu=True))
+    net.finalize()
+    x = synth.synth_input(11, (n, 3, h, w)).abs().clamp(0, 1)
+    net.set_profiling(True)
+    got = net.forward(x.to(cuda_device))[tap].cpu()
+    torch.cuda.synchronize()
+    assert [v for k, v, ms, fl in net.profile() if k == 1][0] == 951009
+    xin = (x[:, perm] * torch.tensor(scale).view(1, 3, 1, 1) + torch.tensor(shift).view(1, 3, 1, 1)).half().double()
+    ref = F.relu(F.conv2d(xin, wt.half().double(), b.double(), padding=1))
+    assert got.shape == ref.shape and _rel(got.double(), ref) < 2e-3
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        assert float((got.double()[sl] - ref[sl]).abs().max() / ref.abs().max()) < 2e-3
