@@ -62,8 +62,12 @@ __device__ __forceinline__ unsigned norm_res_pair(unsigned raw, unsigned res, fl
 
 // PHT = 16: two halo stages, the (scale, shift) tables, eight wave-private transpose patches.  PHT = 32 (tall 16 x 32 patches, 64-channel layers): the two
 // 77 KB stages fill the LDS; the patches alias the stage the tile has just finished with (one more workgroup barrier per tile)
-template <int BN, int PHT = 16>
+// SINGLE (one 64-channel chunk per tile, i.e. Cin = 64): ONE halo stage per workgroup and two workgroups per CU instead of a double-buffered one -- a tile is only
+// nine tap steps long, so with one wave per SIMD the staging and the epilogue of a lone workgroup lie bare; two of them cover each other's.  (With more chunks the
+// accumulators are live while a chunk is staged and all-loads-in-flight staging spills: those shapes keep the double-buffered form.)
+template <int BN, int PHT = 16, bool SINGLE = false>
 constexpr size_t rb_lds_bytes() {
+    if (SINGLE) return PHT == 16 ? (size_t)HALO_ROWS_PAD * ROWB + (size_t)4 * 32 * (64 + 8) * 2 : (size_t)(((PHT + 2) * HALO_W + 7) / 8 * 8) * ROWB;
     return PHT == 16 ? (size_t)C_OFF + (size_t)8 * 32 * (BN / 4 + 8) * 2 : (size_t)2 * (((PHT + 2) * HALO_W + 7) / 8 * 8) * ROWB;
 }
 
@@ -83,10 +87,11 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 // and a wave skips the (shift, phase) blocks that are all zero; the epilogue scatters column blocks to output pixels
 // (2y + py, 2x + px).  MODE 3 (norm + residual, no write-back) exists for this form: y9 = y8 + IN(.) feeds only the first
 // transposed conv.
-template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
+template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16, bool SINGLE = false>
+__global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
     constexpr int PH = PHT, BM = PHT * 16;                              // (shadow the 16-row constants of the file scope)
     constexpr bool ALIAS = PHT > 16;                                    // transpose patches inside the consumed halo stage
+    static_assert(!SINGLE || (MODE == 0 && !CT && WGM * WGN == 4), "single-stage form: plain input, four waves");
     constexpr bool NORM = (MODE & 1) != 0, RES = (MODE & 2) != 0, WB = (MODE & 4) != 0;
     constexpr int NT = WGM * WGN * 64, RPR = NT / 8;   // threads, halo rows staged per loader round
     constexpr int HW_ = CT ? 17 : HALO_W;                               // halo width / height
@@ -225,21 +230,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         stage_norm(cur, 0);
         __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
-    __syncthreads();
     Pend pend[RPS];
-#pragma unroll
-    for (int u = 0; u < RPS; ++u) pend[u] = load_piece(cur, 0, 0);      // (placeholder values: overwritten before their first use)
-
     f16x8 afr[2][TM];
+    if (!SINGLE) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(0, i, 0, 0, 0);
+        for (int r = 0; r < NR; ++r) store_piece(0, 0, r, load_piece(cur, 0, r));
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPS; ++u) pend[u] = load_piece(cur, 0, 0);      // (placeholder values: overwritten before their first use)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(0, i, 0, 0, 0);
+    }
 
     int so = 0;                   // LDS offset of the halo stage of the current chunk (0 or A_BYTES)
     int slot = 0;                 // (scale, shift) slot of the current tile
     for (;;) {
         const TileAt nxt = tile_at(vb + gridDim.x);
+        if (SINGLE) {                    // the tile's whole halo: every load issued before the first is consumed, then the LDS writes, then the barrier
+            Pend pp[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pp[r] = load_piece(cur, 0, r);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) store_piece(0, 0, r, pp[r]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(0, i, 0, 0, 0);
+        }
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int c = 0; c < nchunks; ++c) {
+        for (int c = 0; c < (SINGLE ? 1 : nchunks); ++c) {
             const bool last = c + 1 == nchunks;
             // the chunk staged during this one: the next chunk of this tile, chunk 0 of the next tile, or -- when nothing
             // follows -- chunk 0 of this tile once more (idempotent, never read)
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
 #pragma unroll
                         for (int i = 0; i < TM; ++i) afr[nx][i] = a_frag(so, i, nty, ntx, 0);
                     }
-                    if (kk == 2) {               // halo of the next chunk: RPS pieces per step, written a step after their load
+                    if (!SINGLE && kk == 2) {    // halo of the next chunk: RPS pieces per step, written a step after their load
 #pragma unroll
                         for (int u = 0; u < RPS; ++u) {
                             if (t >= 1 && (t - 1) * RPS + u < NR) store_piece(sslot, A_BYTES - so, (t - 1) * RPS + u, pend[u]);
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
         // fixed butterfly -- no cross-wave step (the four waves of a row write disjoint channel ranges of the record).
         if (!(d.dbg & 4)) {
             constexpr int PCP = WTN + 8;                                   // halves per patch row (64 + 8)
-            f16* patch = (f16*)(smem + (ALIAS ? so : C_OFF)) + wave * (32 * PCP);
+            f16* patch = (f16*)(smem + (ALIAS ? so : (SINGLE ? A_BYTES : C_OFF))) + wave * (32 * PCP);
             const bool relu_now = d.relu && !d.res;
             const bool has_res = d.res != nullptr;
             int fr_e = fr, fh_e = fh, lane_e = lane;            // (opaque copies: keeps the epilogue's addresses out of the
@@ -437,16 +455,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_rb_kernel(const C
             asm volatile("" ::: "memory");
         }
         cur = nxt; vb += gridDim.x; slot ^= 1;
-        so = A_BYTES - so;
+        if (!SINGLE) {
+            so = A_BYTES - so;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+            for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
+        }
     }
 }
 
-template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16>
+template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16, bool SINGLE = false>
 int launch_rb(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PHT - 1) / PHT), ntn = d.CoutPad / BN;
-    constexpr size_t lds = rb_lds_bytes<BN, PHT>();
+    constexpr size_t lds = rb_lds_bytes<BN, PHT, SINGLE>();
+    static_assert(!SINGLE || 2 * lds <= 160 * 1024, "two workgroups per CU");
     static_assert(lds <= 160 * 1024, "LDS budget");
     static int cus = 0;
     if (!cus) {
@@ -454,12 +475,13 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     static const int persist = [] { const char* e = getenv("GDT_RB_PERSIST"); return e ? atoi(e) : 1; }();
-    const int grid = (vblocks < cus || !persist) ? vblocks : cus * (persist > 1 ? persist : 1) / (persist > 1 ? 2 : 1);
-    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
+    int grid = (vblocks < cus || !persist) ? vblocks : cus * (persist > 1 ? persist : 1) / (persist > 1 ? 2 : 1);
+    if (SINGLE) grid = vblocks < 2 * cus ? vblocks : 2 * cus;
+    hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT, SINGLE>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -487,8 +509,9 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
-    if (d.CoutPad == 128) return launch_rb<128, 2, 2, 0>(d, stream);
-    if (d.CoutPad == 64) return launch_rb<64, 4, 1, 0, false, 32>(d, stream);
+    static const int single = [] { const char* e = getenv("GDT_CONV_RB_SINGLE"); return e ? atoi(e) : 1; }();
+    if (d.CoutPad == 128) return (single && d.Cin == 64) ? launch_rb<128, 2, 2, 0, false, 16, true>(d, stream) : launch_rb<128, 2, 2, 0>(d, stream);
+    if (d.CoutPad == 64) return (single && d.Cin == 64) ? launch_rb<64, 4, 1, 0, false, 32, true>(d, stream) : launch_rb<64, 4, 1, 0, false, 32>(d, stream);
     if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
