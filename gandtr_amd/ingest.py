@@ -155,7 +155,8 @@ def ingest_many(images, imsize, mean, std, clahe_clip=None, clahe_grid=8, stream
     per-image form and ignored.  Returns a list of fp32 3 x h x w tensors in input order."""
     if not images:
         return []
-    plans = [_plan(img, imsize) for img in images]
+    sizes = list(imsize) if isinstance(imsize, (list, tuple)) else [imsize] * len(images)      # (per image: the dataset scales cropped queries, genericdataset.py:89-91)
+    plans = [_plan(img, s) for img, s in zip(images, sizes)]
     if clahe_clip is None:
         return resize_many(images, plans, want_u8=False, mean_std=(mean, std), want_chw=True)[1]
     from . import clahe

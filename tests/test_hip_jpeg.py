@@ -169,3 +169,34 @@ def test_corrupted_entropy_data_decodes_to_something_without_harm():
     for t, blob in zip(out[1:-1], bad):
         p = jpeg.parse(blob)
         assert tuple(t.shape) == (p.info.height, p.info.width, 3)
+
+
+def test_images_from_list_mirror(tmp_path):
+    """gandtr_amd.datasets.ImagesFromList against the reference's per-item steps (genericdataset.py:58-99) done with Pillow / numpy: load, crop
+    to the bounding box, imresize scaled by the crop's share of the full image, totensor | normalize"""
+    from gandtr_amd.datasets import ImagesFromList
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    names, bbxs = [], []
+    for i, (w, h) in enumerate([(400, 300), (280, 360), (333, 222)]):
+        names.append("im%d.jpg" % i)
+        _picture(w, h, 30 + i).save(str(tmp_path / names[-1]), "JPEG", quality=88, subsampling=i % 3)
+        bbxs.append(None if i == 1 else (20.4 + i, 31.6, w - 40.2, h - 25.5))
+    ds = ImagesFromList(str(tmp_path), names, imsize=200, bbxs=bbxs, transform=(mean, std), device="cuda:0")
+    assert len(ds) == 3
+    got = ds.batch(range(3))
+    for i, g in enumerate(got):
+        img = Image.open(str(tmp_path / names[i])).convert("RGB")
+        full = max(img.size)
+        if bbxs[i]:
+            img = img.crop(bbxs[i])
+            img.thumbnail((200 * max(img.size) / full,) * 2, Image.LANCZOS)
+        else:
+            img.thumbnail((200, 200), Image.LANCZOS)
+        want = (np.asarray(img).astype(np.float32) / 255.0 - np.array(mean, np.float32)) / np.array(std, np.float32)
+        assert tuple(g.shape) == (3, want.shape[0], want.shape[1]), (i, g.shape, want.shape)
+        assert np.abs(g.cpu().numpy() - want.transpose(2, 0, 1)).max() < 1e-5
+    assert torch.equal(ds[1], got[1])
+    plain = ImagesFromList("", [str(tmp_path / names[0])], device="cuda:0")          # no imsize, no transform: the decoded pixels
+    assert np.array_equal(plain[0].cpu().numpy(), np.asarray(Image.open(str(tmp_path / names[0])).convert("RGB")))
+    with pytest.raises(RuntimeError, match="0 images"):
+        ImagesFromList("", [])
