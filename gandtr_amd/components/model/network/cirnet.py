@@ -92,6 +92,21 @@ class ImageRetrievalNet(HipBacked, nn.Module):
         net = self._hip_net(("embed", prec), lambda sd, dev: engine.build_embedder(sd, dev, precision=prec))
         return net.forward(x, scale=scale)[net.out_slot].t()      # N x D storage, D x N view (imageretrievalnet.py:123)
 
+    def forward_many(self, xs):
+        """``[self(x) for x in xs]`` with the HIP forwards of the list issued concurrently (engine.HipNet.forward_many): the levels of a
+        multi-scale pyramid are independent and each is too small to fill the chip."""
+        from .... import engine
+        if self._hip_device().type != "cuda" or len(xs) < 2:
+            return [self(x) for x in xs]
+        if self.lwhiten is not None or self.whiten is not None or not isinstance(self.pool, GeM) or \
+                self.meta.get("architecture") not in ("vgg16", "resnet50", "resnet101", "resnet152"):
+            return [self(x) for x in xs]                          # (raises the same NotImplementedError as the single call)
+        self._hip_check_inference()
+        prec = self._hip_precision()
+        net = self._hip_net(("embed", prec), lambda sd, dev: engine.build_embedder(sd, dev, precision=prec))
+        pairs = [(x.tensor, x.scale) if isinstance(x, ScaledInput) else (x, None) for x in xs]
+        return [outs[net.out_slot].t() for outs in net.forward_many(pairs)]
+
     def meta_repr(self):
         lines = ["  (meta): dict("]
         for k in ("architecture", "local_whitening", "pooling", "regional", "whitening", "outputdim", "mean", "std"):

@@ -219,6 +219,48 @@ class HipNet:
             self._launch(x, n, h, w, rh, rw, rscale, self._ws, outs)
         return outs
 
+    def forward_many(self, inputs):
+        """Several independent forwards -- ``inputs`` = [(x, scale or None), ...], e.g. the levels of the multi-scale pyramid
+        (CirMultiscaleAggregation, wrapper.py:225-263) -- issued on one side stream each, every one with its own scratch buffer, and joined
+        on the caller's stream.  A level at batch 8 leaves most of the chip idle (layer3 of ResNet-101 at scale 1/2: 32 patch tiles for
+        256 CUs); the levels' kernels fill each other's gaps.  Results are those of ``forward`` called level by level."""
+        if not self._finalized:
+            raise RuntimeError("HipNet.forward_many before finalize()")
+        if len(inputs) == 1 or getattr(self, "_profiling", False) or os.environ.get("GANDTR_HIP_CONCURRENT_LEVELS", "1") == "0":
+            return [self.forward(x, scale=s) for x, s in inputs]
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        pools = self.__dict__.setdefault("_side", {"streams": [], "ws": []})
+        while len(pools["streams"]) < len(inputs):
+            pools["streams"].append(torch.cuda.Stream(device=dev))
+            pools["ws"].append(None)
+        results = []
+        with torch.cuda.device(dev):
+            for k, (x, scale) in enumerate(inputs):
+                if x.dim() != 4 or x.shape[1] != self.in_channels:
+                    raise ValueError("expected an N x %s x H x W input, got %s" % (self.in_channels, tuple(x.shape)))
+                x = x.to(dev).contiguous().float()
+                n, _, h, w = x.shape
+                rh, rw = self.resized_size(h, w, scale)
+                rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
+                need = self.workspace_bytes(n, rh, rw)
+                shapes = self.output_shapes(n, rh, rw)
+                st = pools["streams"][k]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    if pools["ws"][k] is None or pools["ws"][k].numel() < need:
+                        pools["ws"][k] = None
+                        pools["ws"][k] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+                    self._launch(x, n, h, w, rh, rw, rscale, pools["ws"][k], outs)
+                    x.record_stream(st)
+                results.append(outs)
+            for k in range(len(inputs)):
+                cur.wait_stream(pools["streams"][k])
+                for o in results[k]:
+                    o.record_stream(cur)
+        return results
+
     def _capture(self, x, key, need, shapes):
         n, h, w, rh, rw, rscale = key
         try:

@@ -146,6 +146,8 @@ class SingleNetwork(Network):
         if images is None:
             return None
         if isinstance(images, list):
+            if not params and len(images) > 1 and hasattr(self.model, "forward_many") and all(x is not None for x in images):
+                return self.model.forward_many([_as_model_input(x) for x in images])          # pyramid levels: concurrent on a HIP device
             return [None if x is None else self.model(_as_model_input(x), **params) for x in images]
         return self.model(_as_model_input(images), **params)
 

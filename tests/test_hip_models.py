@@ -279,3 +279,20 @@ def test_invalid_inputs_raise(cuda_device):
     emb = build_embedder(synth.vgg16_state(0, width_div=4), cuda_device)
     with pytest.raises(ValueError):
         emb.forward(torch.zeros(1, 3, 8, 8, device=cuda_device))           # four max-pools leave nothing
+
+
+def test_pyramid_levels_issued_concurrently_equal_level_by_level(cuda_device):
+    """HipNet.forward_many (the multi-scale wrapper's levels on one side stream each, own scratch buffers) returns exactly what forward
+    returns level by level -- same kernels, same geometry, only the issue order across streams differs -- also when called repeatedly
+    (scratch buffers reused) and interleaved with plain forwards"""
+    from gandtr_amd import engine
+    net = engine.build_embedder(synth.resnet101_state(0), cuda_device)
+    x = synth.synth_input(3, (2, 3, 320, 416)).to(cuda_device)
+    levels = [(x, None), (x, 2 ** -0.5), (x, 0.5), (x, 2 ** 0.5)]
+    want = [net.forward(xx, scale=s)[net.out_slot].clone() for xx, s in levels]
+    for _ in range(3):
+        got = net.forward_many(levels)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g[net.out_slot], w)
+        assert torch.equal(net.forward(x)[net.out_slot], want[0])
