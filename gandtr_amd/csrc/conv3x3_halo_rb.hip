@@ -505,6 +505,8 @@ bool gdt_conv_halo_rb_eligible(const ConvLaunch& d) {
     return gdt_conv_halo_eligible(d);
 }
 
+static bool narrow_ok() { static const int v = [] { const char* e = getenv("GDT_CONV_RB128"); return e ? atoi(e) : 1; }(); return v != 0; }
+
 int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
@@ -512,7 +514,14 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int single = [] { const char* e = getenv("GDT_CONV_RB_SINGLE"); return e ? atoi(e) : 1; }();
     if (d.CoutPad == 128) return (single && d.Cin == 64) ? launch_rb<128, 2, 2, 0, false, 16, true>(d, stream) : launch_rb<128, 2, 2, 0>(d, stream);
     if (d.CoutPad == 64) return (single && d.Cin == 64) ? launch_rb<64, 4, 1, 0, false, 32, true>(d, stream) : launch_rb<64, 4, 1, 0, false, 32>(d, stream);
-    if (!d.in_norm) return launch_rb<256, 2, 4, 0>(d, stream);
+    if (!d.in_norm) {
+        // few patches (small images / small batches: ResNet layer3 / 4 on 256^2 inputs, the small levels of a pyramid): 128-column tiles of the four-wave form
+        // double the number of workgroups -- every CU gets one wave per SIMD instead of half the CUs getting two
+        static const int split_below = [] { const char* e = getenv("GDT_RB_SPLIT_BELOW"); return e ? atoi(e) : 192; }();
+        const long tiles256 = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16) * (d.CoutPad / 256);
+        if (narrow_ok() && tiles256 < split_below && !d.in_res && !d.in_out && !d.stats) return launch_rb<128, 2, 2, 0>(d, stream);
+        return launch_rb<256, 2, 4, 0>(d, stream);
+    }
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
 }
