@@ -374,3 +374,40 @@ def test_vgg_first_conv_from_the_fp32_image(cuda_device, n, h, w):
     assert got.shape == ref.shape and _rel(got.double(), ref) < 2e-3
     for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
         assert float((got.double()[sl] - ref[sl]).abs().max() / ref.abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("cin,cout,reflect,pool,shape", [
+    (64, 64, False, True, (2, 150, 176)),       # tall 16 x 32 patches, last patch row 22 of 32 deep, single-stage form, fused pool
+    (64, 64, True, False, (4, 112, 90)),        # reflect padding, ragged in both directions (112 = 3.5 patches of 32, 90 = 5.6 of 16)
+    (64, 128, False, False, (2, 150, 170)),     # single-stage form, 2 x 2 waves
+    (128, 128, False, True, (4, 108, 120)),     # two chunks: double-buffered four-wave form, fused pool
+    (128, 128, True, False, (2, 150, 170)),
+])
+def test_conv3x3_small_channel_forms_of_the_patch_kernel(cuda_device, cin, cout, reflect, pool, shape):
+    """conv3x3_halo_rb.hip's four-wave forms for 64 / 128 output channels (VGG16 conv1_2 / conv2_x, the HED trunk): ragged patch edges, reflect
+    padding, the fused 2 x 2 max pool, against fp64 on the fp16 tensors the layer consumed; and that these forms are the ones that ran."""
+    from gandtr_amd.engine import HipNet
+    n, h, w = shape
+    net = HipNet(cuda_device)
+    t = net.input(3)
+    a = net.conv(t, synth._normal(0, "w0", (cin, 3, 1, 1), 0.7), relu=True)
+    tap_in = net.output_nchw(a)
+    wt, b = synth._normal(0, "w", (cout, cin, 3, 3), math.sqrt(2.0 / (cin * 9))), synth._normal(0, "b", (cout,), 0.2)
+    o = net.conv(a, wt, b, pad=1, reflect=reflect, relu=True)
+    if pool:
+        o = net.maxpool(o, 2, 2)
+    tap = net.output_nchw(o)
+    net.finalize()
+    x = synth.synth_input(8, (n, 3, h, w))
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert 910000 + cout in [v for k, v, ms, fl in net.profile() if k == 1]
+    xin = outs[tap_in].double().cpu()
+    xi = F.pad(xin, (1,) * 4, mode="reflect") if reflect else xin
+    ref = F.relu(F.conv2d(xi, wt.half().double(), b.double(), padding=0 if reflect else 1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    got = outs[tap].double().cpu()
+    assert got.shape == ref.shape and _rel(got, ref) < 2e-3
+    assert torch.equal(outs[tap], net.forward(x.to(cuda_device))[tap])
