@@ -312,7 +312,10 @@ bool gdt_conv_halo_eligible(const ConvLaunch& d) {
     const int bn = d.CoutPad % 256 == 0 ? 256 : (d.CoutPad % 128 == 0 ? 128 : 64);
     // padded patches waste work on ragged sizes: require >= 85 % useful pixels
     const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
-    static const int min_tiles = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 128; }();   // (batch-1 sweeps: 64-128 best; 512 loses 25 % on a 1024^2 image)
+    static const int min_env = [] { const char* e = getenv("GDT_CONV_MIN_TILES"); return e ? atoi(e) : 0; }();
+    // (batch-1 sweeps of the first-generation kernel: 64-128 best, 512 loses 25 % on a 1024^2 image.  With fragment-ordered weights the layer runs on
+    // conv3x3_halo_rb.hip, whose 128-column four-wave tiles keep winning down to 16 patches: GeM-ResNet-101 8 x 512^2 2.38 -> 2.15 ms, 1 x 1024^2 2.17 -> 2.03)
+    const int min_tiles = min_env ? min_env : ((d.w_frag && !d.in_norm && !d.stats) ? 16 : 128);       // (the folded-norm modes only exist in the eight-wave form)
     return tiles * (d.CoutPad / bn) >= min_tiles && useful >= 0.85;
 }
 
