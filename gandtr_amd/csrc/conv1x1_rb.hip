@@ -312,7 +312,10 @@ int gdt_launch_conv_1x1_rb(const ConvLaunch& d_in, hipStream_t stream) {
     static const int max_depth = [] { const char* e = getenv("GDT_CONV_1X1_DEPTH"); return e ? atoi(e) : 4; }();
     static const int wide = [] { const char* e = getenv("GDT_CONV_1X1_WIDE"); return e ? atoi(e) : 1; }();
     if (d.res) return nk > 1 ? launch_1x1<true, 2, 2>(d, stream) : launch_1x1<true, 1, 2>(d, stream);
-    if (wide && nk > 1 && d.CoutPad % 256 == 0) return launch_1x1<false, 2, 4>(d, stream);
+    // (the 128 x 256 tile halves the weight stream per MFMA but also the number of workgroups: below ~one per CU the 128 x 128 tile fills the chip better)
+    static const int wide_min = [] { const char* e = getenv("GDT_CONV_1X1_WIDE_MIN"); return e ? atoi(e) : 256; }();
+    const long wide_tiles = (long)((d.M + BM - 1) / BM) * (d.CoutPad / 256);
+    if (wide && nk > 1 && d.CoutPad % 256 == 0 && wide_tiles >= wide_min) return launch_1x1<false, 2, 4>(d, stream);
     if (nk % 4 == 0 && max_depth >= 4) return launch_1x1<false, 4, 2>(d, stream);
     return nk > 1 ? launch_1x1<false, 2, 2>(d, stream) : launch_1x1<false, 1, 2>(d, stream);
 }
