@@ -499,7 +499,8 @@ bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W) {
     else return false;
     if (H % ph != 0 || W % PW != 0) return false;
     if ((long)N * H * W * C >= (1L << 31)) return false;
-    return (long)N * (H / ph) * (W / PW) >= 256;
+    static const int min_tiles = [] { const char* m = getenv("GDT_BNECK_MIN_TILES"); return m ? atoi(m) : 256; }();
+    return (long)N * (H / ph) * (W / PW) >= min_tiles;
 }
 
 int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
