@@ -36,14 +36,19 @@ from gandtr_amd.tools import synth                    # noqa: E402
 
 
 def rate(fn, units, steps=8, warmup=2):
+    """(units per second, ms per call).  Each call is timed on its own and the MEDIAN is reported: a single stall inside a short window -- a hipMalloc when the
+    caching allocator regrows after the previous configuration's empty_cache() -- moved an 8-step mean by 3-4 ms ("the config-3 regression")."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         fn()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = times[len(times) // 2] if steps >= 3 else sum(times) / len(times)
     return round(units / dt, 1), round(dt * 1e3, 2)
 
 
