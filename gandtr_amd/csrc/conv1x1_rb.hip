@@ -20,6 +20,10 @@
 
 #include "gdt_common.h"
 
+#ifndef GDT_1X1_NT_RES
+#define GDT_1X1_NT_RES 0       // 1: the residual (its last use in a ResNet block) is fetched non-temporal
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;                       // bytes per LDS row (64 halves of K)
@@ -157,7 +161,15 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) { bool ok; const unsigned o = out_off(i, qq, ok); rv[RES ? i : 0][qq] = *(const f16x8*)(d.res + o); }
+                for (int qq = 0; qq < 4; ++qq) {
+                    bool ok; const unsigned o = out_off(i, qq, ok);
+#if GDT_1X1_NT_RES
+                    typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+                    rv[RES ? i : 0][qq] = __builtin_bit_cast(f16x8, __builtin_nontemporal_load((const nt_u32x4*)(d.res + o)));
+#else
+                    rv[RES ? i : 0][qq] = *(const f16x8*)(d.res + o);
+#endif
+                }
         }
         auto k_step = [&](Pend& P, const int s, auto last_tag) {
             constexpr bool last = decltype(last_tag)::value;
