@@ -129,3 +129,21 @@ def test_parser_survives_truncated_and_corrupted_files():
             data, seg = _scan(p)
             assert len(data) == p.info.scan_capacity and seg[-1] + 16 <= p.info.scan_capacity and all(a <= b2 for a, b2 in zip(seg, seg[1:]))
     assert accepted > 50 and refused > 1000
+
+
+def test_images_from_list_constructor_contract():
+    """the dataset mirror refuses what it does not mirror and keeps the reference's empty-list error (genericdataset.py:54-55); no device needed"""
+    from gandtr_amd.datasets import ImagesFromList
+    with pytest.raises(RuntimeError, match="0 images"):
+        ImagesFromList("", [], device="cpu")
+    with pytest.raises(NotImplementedError):
+        ImagesFromList("store.h5", ["a.jpg"], device="cpu")
+    with pytest.raises(NotImplementedError):
+        ImagesFromList("", ["a.jpg"], load_images_with_bbx=True, device="cpu")
+    ds = ImagesFromList("/data", ["a.jpg", "sub/b.jpg"], imsize=362, device="cpu")
+    assert len(ds) == 2 and ds.images_fn == ["/data/a.jpg", "/data/sub/b.jpg"] and "Number of images: 2" in repr(ds)
+    with pytest.raises(OSError):
+        ds.batch([0])                                   # a missing file is the loader's error, as in the reference (genericdataset.py:70-75)
+    blob = _encode(np.zeros((16, 16, 3), np.uint8), quality=80)
+    with pytest.raises(ValueError, match="HIP device"):
+        ImagesFromList("", [blob], device="cpu").batch([0])      # decoding needs the device: there is no host path
