@@ -84,7 +84,9 @@ struct BneckLaunch {
     int N, H, W;
 };
 
-template <int C, int MID, int PH, int CIN = C, bool DS = false>
+// RAGGED: maps the patches do not tile exactly (real images: H, W arbitrary) -- the last patch row / column hangs over the image: its x loads are clamped, r is
+// zeroed there (as at every image border), residual fetches are clamped and the stores of pixels outside the image are masked off
+template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
 __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, const int ntiles) {
     using G = Geo<C, MID, PH, CIN, DS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    const int tiles_x = d.W / PW, tiles_y = d.H / PH, tpi = tiles_x * tiles_y;
+    const int tiles_x = (d.W + PW - 1) / PW, tiles_y = (d.H + PH - 1) / PH, tpi = tiles_x * tiles_y;
 
     // XCD-chunked persistent schedule (conv_head7.hip): the CUs of one XCD hold neighbouring patches, whose halos overlap in its L2
     const int per_xcd = (ntiles + 7) >> 3, S = (int)gridDim.x >> 3;
@@ -266,7 +268,13 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
         const int pl = lane >> 3, pc = lane & 7;
         auto res_off = [&](int jb, int i) -> size_t {           // row this lane stores / fetches the residual of: output pixel 8 i + (lane >> 3) of
             const int prow = (epb0 + jb) * 32 + 8 * i + pl;     // pixel block epb0 + jb (patch row prow / 16, column prow % 16), 16-byte piece lane & 7
-            return ((size_t)((n * d.H + y0 + (prow >> 4)) * d.W + x0 + (prow & 15))) * C + ecp * 64 + pc * 8;
+            const int y = y0 + (prow >> 4), x = x0 + (prow & 15);
+            if (RAGGED) return ((size_t)((n * d.H + min(y, d.H - 1)) * d.W + min(x, d.W - 1))) * C + ecp * 64 + pc * 8;       // (a valid address; see res_ok)
+            return ((size_t)((n * d.H + y) * d.W + x)) * C + ecp * 64 + pc * 8;
+        };
+        auto res_ok = [&](int jb, int i) -> bool {
+            const int prow = (epb0 + jb) * 32 + 8 * i + pl;
+            return !RAGGED || ((y0 + (prow >> 4) < d.H) & (x0 + (prow & 15) < d.W));
         };
 
         // ================================================================ 3x3: t = ReLU(W_3 (*) r + b_3)
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
                     f16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (f16)fmaxf((float)v[e] + (DS ? 0.f : (float)res[jb & 1][i][e]), 0.f);
-                    *(f16x8*)(d.y + goff[i]) = o;
+                    if (res_ok(jb, i)) *(f16x8*)(d.y + goff[i]) = o;
                 }
             }
         }
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
 #endif
 }
 
-template <int C, int MID, int PH, int CIN = C, bool DS = false>
+template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
 int launch(const BneckLaunch& d, hipStream_t stream) {
     using G = Geo<C, MID, PH, CIN, DS>;
     static int cus = 0;
@@ -458,9 +466,9 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
         GDT_CHECK_HIP(hipGetDevice(&dev));
         GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH, CIN, DS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH, CIN, DS, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
     }
-    const int ntiles = d.N * (d.W / PW) * (d.H / PH);
+    const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
     const int grid = min(cus, (ntiles + 7) / 8 * 8);
 #ifdef GDT_BNECK_STAMP
     static unsigned long long* sb = nullptr;
@@ -468,7 +476,7 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
     if (!sb) GDT_CHECK_HIP(hipMalloc((void**)&sb, (size_t)cus * NWAVE * 4 * 8));
     BneckLaunch ds = d; ds.stamps = sb;
     GDT_CHECK_HIP(hipMemsetAsync(sb, 0, (size_t)cus * NWAVE * 4 * 8, stream));
-    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS>), dim3(grid), dim3(NT), G::LDS, stream, ds, ntiles);
+    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS, RAGGED>), dim3(grid), dim3(NT), G::LDS, stream, ds, ntiles);
     if (++calls % 50 < 3) {
         GDT_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)grid * NWAVE * 4);
@@ -481,7 +489,7 @@ int launch(const BneckLaunch& d, hipStream_t stream) {
     }
     return GDT_OK;
 #endif
-    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS>), dim3(grid), dim3(NT), G::LDS, stream, d, ntiles);
+    hipLaunchKernelGGL((conv_bneck_kernel<C, MID, PH, CIN, DS, RAGGED>), dim3(grid), dim3(NT), G::LDS, stream, d, ntiles);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
@@ -497,18 +505,19 @@ bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W) {
     if (C == 256 && mid == 64 && (cin == 256 || cin == 64)) ph = 16;        // cin 64: the projection-shortcut form (layer1's first block)
     else if (C == 512 && mid == 128 && cin == 512) ph = 8;
     else return false;
-    if (H % ph != 0 || W % PW != 0) return false;
+    // patches that hang over the image (ragged form) may waste at most 15 % of the patch area
+    if ((double)H * W / ((double)((H + ph - 1) / ph * ph) * ((W + PW - 1) / PW * PW)) < 0.85) return false;
     if ((long)N * H * W * C >= (1L << 31)) return false;
     static const int min_tiles = [] { const char* m = getenv("GDT_BNECK_MIN_TILES"); return m ? atoi(m) : 256; }();
-    return (long)N * (H / ph) * (W / PW) >= min_tiles;
+    return (long)N * ((H + ph - 1) / ph) * ((W + PW - 1) / PW) >= min_tiles;
 }
 
 int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
                      const f16* wd, const float* bd, int cin, int C, int mid, int N, int H, int W, hipStream_t stream) {
     BneckLaunch d{nullptr, x, y, wr, w3, we, br, b3, be, wd, bd, N, H, W};
-    if (cin == 256 && C == 256 && mid == 64 && !wd) return launch<256, 64, 16>(d, stream);
-    if (cin == 512 && C == 512 && mid == 128 && !wd) return launch<512, 128, 8>(d, stream);
-    if (cin == 64 && C == 256 && mid == 64 && wd && bd) return launch<256, 64, 16, 64, true>(d, stream);
+    if (cin == 256 && C == 256 && mid == 64 && !wd) return (H % 16 || W % PW) ? launch<256, 64, 16, 256, false, true>(d, stream) : launch<256, 64, 16>(d, stream);
+    if (cin == 512 && C == 512 && mid == 128 && !wd) return (H % 8 || W % PW) ? launch<512, 128, 8, 512, false, true>(d, stream) : launch<512, 128, 8>(d, stream);
+    if (cin == 64 && C == 256 && mid == 64 && wd && bd) return (H % 16 || W % PW) ? launch<256, 64, 16, 64, true, true>(d, stream) : launch<256, 64, 16, 64, true>(d, stream);
     gdt_set_error("gdt_launch_bneck: unsupported shape");
     return GDT_ERR_INVALID;
 }

@@ -41,7 +41,8 @@ def _ref_block(x, w):
     return F.relu(F.conv2d(t, we, be) + x)
 
 
-@pytest.mark.parametrize("C,mid,n,h,w", [(256, 64, 4, 128, 128), (512, 128, 4, 64, 128), (256, 64, 1, 256, 256)])
+@pytest.mark.parametrize("C,mid,n,h,w", [(256, 64, 4, 128, 128), (512, 128, 4, 64, 128), (256, 64, 1, 256, 256),
+                                          (256, 64, 4, 120, 136), (512, 128, 4, 68, 136), (256, 64, 3, 171, 250)])     # ragged maps: the last patch row / column hangs over the image
 def test_fused_bottleneck(cuda_device, C, mid, n, h, w, monkeypatch):
     net, taps, ws = _block_net(cuda_device, C, mid, nblocks=2)
     x = synth.synth_input(5, (n, 3, h, w))
@@ -75,11 +76,13 @@ def test_fused_bottleneck(cuda_device, C, mid, n, h, w, monkeypatch):
     assert d < 2e-3, d
 
 
+@pytest.mark.parametrize("shape", [(4, 128, 128), (4, 120, 136)], ids=["whole-patches", "ragged"])
 @pytest.mark.parametrize("projection_first", [True, False])
-def test_fused_bottleneck_projection_shortcut(cuda_device, projection_first):
+def test_fused_bottleneck_projection_shortcut(cuda_device, projection_first, shape):
     """layer1's first block: 64 -> (64, 64) -> 256 with a 1x1 projection of the input as the shortcut (torchvision `downsample`); the
     projection is emitted before the reduce conv by engine.py (either order is recognised) -- one launch, against fp64"""
-    C, cin, mid, n, h, w = 256, 64, 64, 4, 128, 128
+    C, cin, mid = 256, 64, 64
+    n, h, w = shape
     net = HipNet(cuda_device, "f16")
     t = net.input(3)
     x = net.conv(t, _g("w0", (cin, 3, 1, 1), 0.5), _g("b0", (cin,), 0.3), relu=True)
