@@ -519,7 +519,12 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
         // double the number of workgroups -- every CU gets one wave per SIMD instead of half the CUs getting two
         static const int split_below = [] { const char* e = getenv("GDT_RB_SPLIT_BELOW"); return e ? atoi(e) : 192; }();
         const long tiles256 = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16) * (d.CoutPad / 256);
-        if (narrow_ok() && tiles256 < split_below && !d.in_res && !d.in_out && !d.stats) return launch_rb<128, 2, 2, 0>(d, stream);
+        // ... and so do tile counts that leave the last round of the persistent walk half empty (384 patches on 256 CUs: two rounds for 1.5 rounds of work):
+        // the narrow form is ~0.85x as efficient per tile but its 2x finer grain can more than make up for that
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256; return n / 8 * 8; }();
+        auto fill = [&](long t) { return (double)t / (double)((t + cus - 1) / cus * cus); };
+        const bool tail = fill(tiles256) < 0.85 * fill(2 * tiles256) - 0.02;
+        if (narrow_ok() && (tiles256 < split_below || tail) && !d.in_res && !d.in_out && !d.stats) return launch_rb<128, 2, 2, 0>(d, stream);
         return launch_rb<256, 2, 4, 0>(d, stream);
     }
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }

@@ -6,7 +6,7 @@ from gandtr_amd import engine
 from gandtr_amd.tools import synth
 dev = torch.device("cuda:0")
 net = engine.build_embedder(synth.resnet101_state(0), dev)
-for shape in [(1, 3, 1024, 1024), (8, 3, 512, 512), (8, 3, 724, 724), (128, 3, 256, 256)]:
+for shape in [(1, 3, 1024, 1024), (8, 3, 512, 512), (8, 3, 724, 724), (128, 3, 256, 256), (32, 3, 1024, 683)]:
     x = synth.synth_input(1, shape).to(dev)
     for _ in range(3): net.forward(x)
     net.set_profiling(True)
