@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_r
                     f16x8 v = __builtin_elementwise_max(*(const f16x8*)r0, *(const f16x8*)(r0 + PCP));
                     v = __builtin_elementwise_max(v, __builtin_elementwise_max(*(const f16x8*)(r0 + 16 * PCP), *(const f16x8*)(r0 + 17 * PCP)));
                     const int y = cur.y0 + prow, x = cur.x0 + 2 * pc;
-                    if ((y < d.H) & (x < d.W) & (col < d.Cout))
+                    if ((y + 1 < d.H) & (x + 1 < d.W) & (col < d.Cout))        // (odd H / W: the last row / column has no partner and is dropped, as MaxPool2d(2, 2) does)
                         *(f16x8*)(d.out + ((long)((cur.n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
                     continue;
                 }

@@ -77,7 +77,8 @@ __device__ __forceinline__ void conv_epilogue_f16(const ConvLaunch& d, const f32
             if (ok && col < d.Cout) {
                 const long q = pix / d.W; const int x = (int)(pix - q * d.W);
                 const long n = q / d.H; const int y = (int)(q - n * d.H);
-                *(f16x8*)(d.out + (((n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
+                if ((y + 1 < d.H) & (x + 1 < d.W))          // (odd H / W: the last row / column is dropped, as MaxPool2d(2, 2) does)
+                    *(f16x8*)(d.out + (((n * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) * d.Cout + col)) = v;
             }
         }
         return;

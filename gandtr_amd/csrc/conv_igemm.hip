@@ -298,11 +298,11 @@ bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d) {
     return d.Cin == 64 && (d.OHg * d.OWg) % 256 == 0 && d.M % 256 == 0;
 }
 
-// A fused 2x2 max pool needs a patch kernel (16x16 patches: conv3x3_halo_rb.hip / conv3x3_halo.hip), even H and W, and a plain
+// A fused 2x2 max pool needs a patch kernel (16x16 patches: conv3x3_halo_rb.hip / conv3x3_halo.hip) and a plain
 // epilogue (no statistics, residual or write-back).
 bool gdt_conv_pool2_eligible(const ConvLaunch& d) {
     static const int mode = [] { const char* e = getenv("GDT_CONV_POOL"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || (d.H & 1) || (d.W & 1) || d.stats || d.res || d.in_out || d.out_f32 || d.phase_cout) return false;
+    if (mode == 0 || d.H < 2 || d.W < 2 || d.stats || d.res || d.in_out || d.out_f32 || d.phase_cout) return false;
     return gdt_conv_halo_rb_eligible(d) || gdt_conv_halo_eligible(d);
 }
 

@@ -90,7 +90,8 @@ def test_conv3x3_persistent_halo_kernel(cuda_device, cfg):
     assert _rel(got, ref) < (4e-3 if bn else 2e-3), (cfg, _rel(got, ref))
 
 
-@pytest.mark.parametrize("cin,cout,shape", [(256, 256, (8, 128, 128)), (64, 64, (8, 128, 128)), (128, 128, (9, 60, 128)), (256, 512, (8, 96, 96))])
+@pytest.mark.parametrize("cin,cout,shape", [(256, 256, (8, 128, 128)), (64, 64, (8, 128, 128)), (128, 128, (9, 60, 128)), (256, 512, (8, 96, 96)),
+                                            (64, 64, (4, 150, 171)), (256, 256, (8, 127, 128)), (128, 128, (4, 109, 121))])      # odd sizes: the pool drops the last row / column
 def test_conv_relu_maxpool_fused(cuda_device, cin, cout, shape):
     """VGG16 stage ends (Conv2d 3x3 + ReLU + MaxPool2d(2, 2), torchvision cfg "D"): the pool runs in the conv epilogue of the
     patch kernels (conv3x3_halo_rb.hip / conv_epilogue.h) and the full-resolution tensor is never written."""
