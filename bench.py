@@ -182,18 +182,19 @@ def conv_roofline(net, x, steps=3, traffic_key=None):
     for _ in range(steps):
         net.forward(x)
         torch.cuda.synchronize()
-        for kind, variant, ms, fl in net.profile():
+        for (kind, variant, ms, fl), by in zip(net.profile(), net.profile_bytes()):
             all_ms += ms
             if kind == 1 and fl > 0:          # (convs fused into a preceding launch -- the Bottleneck kernel -- carry no FLOPs of their own)
-                e = per.setdefault(variant, [0.0, 0.0, 0])
-                e[0] += ms; e[1] += fl; e[2] += 1
+                e = per.setdefault(variant, [0.0, 0.0, 0, 0.0])
+                e[0] += ms; e[1] += fl; e[2] += 1; e[3] += by
     net.set_profiling(False)
-    variant, (tot_ms, tot_fl, launches) = max(per.items(), key=lambda kv: kv[1][0])
+    variant, (tot_ms, tot_fl, launches, tot_by) = max(per.items(), key=lambda kv: kv[1][0])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(kernel_name(variant), traffic_key),
             "kernel": kernel_name(variant), "launches_per_step": launches // steps,
             "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3),
+            "algorithmic_bytes_per_launch": round(tot_by / max(1, launches)),
             "all_conv_kernels": {kernel_name(v): {"ms_per_step": round(e[0] / steps, 3), "tflops": round(e[1] / max(e[0], 1e-9) / 1e9, 1)}
                                  for v, e in sorted(per.items())}}
 
@@ -430,14 +431,16 @@ def main():
         dt2 = timed(step, a.steps, a.warmup, dev, distributed)
         r_dps = n_total * a.steps / dt2
         roof2 = conv_roofline(emb, xe) if rank == 0 else None
-        if roof2 is not None and roof2.get("kernel") == "conv1x1_rb_kernel":
-            # the Bottleneck 1x1 convs are HBM-bound, not MFMA-bound: algorithmic bytes of the 58 launches of one forward (fp16 in + out
-            # + residual, weights negligible: 1.274 GB per 1024^2 image over the 64 launches) over their summed launch time
-            bytes_1x1 = 1.274e9 * a.r101_batch
+        if roof2 is not None and roof2.get("kernel", "").startswith("conv1x1"):
+            # the Bottleneck 1x1 convs are HBM-bound, not MFMA-bound: algorithmic bytes (fp16 input once, output once, residual once,
+            # weights once -- summed by the library over exactly the launches that were timed, gdt_net_profile_read_bytes) over their
+            # summed launch time
+            bytes_1x1 = roof2["algorithmic_bytes_per_launch"] * roof2["launches_per_step"]
             t_1x1 = roof2["avg_launch_ms"] * 1e-3 * roof2["launches_per_step"]
             roof2["hbm_view"] = {"bound": "hbm", "achieved": round(bytes_1x1 / t_1x1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(bytes_1x1 / t_1x1 / 8e12, 4),
-                                 "note": "algorithmic bytes of every launch of this kernel in one forward / their summed time"}
+                                 "note": "algorithmic bytes of the timed launches of this kernel in one forward (%.3f GB) / their summed time"
+                                         % (bytes_1x1 / 1e9)}
         secondary = {"metric": "descriptors/sec GeM-ResNet101 single-scale @1024x1024", "value": round(r_dps, 2),
                      "unit": "descriptors/s", "ms_per_step": round(dt2 / a.steps * 1e3, 3), "dtype": "f16",
                      "config": {"workload": "gem_resnet101 forward + GeM + L2N (+ RCCL all-gather when N>1), synthetic 3x1024x1024",

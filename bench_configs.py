@@ -117,18 +117,22 @@ def sharded_main(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / steps
 
-    out = {"n_gpus": world, "backend": dist.get_backend(), "dry_run": dry}
+    out = {"n_gpus": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "dry_run": dry}
     tmp = tempfile.mkdtemp()
     steps, warmup = (1, 0) if dry else (args.steps, 1)
     with torch.no_grad():
         # ---- c3: multi-scale + whitening, batch-sharded, one all-gather
         per_rank, side = (2, 64) if dry else (8, 1024)
-        x = synth.synth_input(4, (per_rank * world, 3, side, side)).to(dev)          # every rank synthesises the same global batch
+        # (--global-batch: a global batch that the ranks do not divide -- contiguous chunks of ceil(N / world) images, the last chunk short or
+        #  empty, zero-padded for the collective and trimmed afterwards: sharding.chunk_bounds / all_gather_descriptors)
+        n_glob = args.global_batch if args.global_batch else per_rank * world
+        per_rank = (n_glob + world - 1) // world
+        x = synth.synth_input(4, (n_glob, 3, side, side)).to(dev)          # every rank synthesises the same global batch
         for tag, scales in (("hub_default", True), ("sms", "sms")):
             net = _c3_network(dev, scales, tmp)
             dt = timed(lambda: sharding.embed_sharded(net, x), steps, warmup)
             got = sharding.embed_sharded(net, x)
-            rec = {"descriptors_per_s": round(per_rank * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": per_rank * world,
+            rec = {"descriptors_per_s": round(n_glob / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": n_glob,
                    "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
             if dry:            # the multi-GPU contract: gathered == single-process result over the same chunks, bit for bit, on EVERY rank
                 ref = sharding.descriptors_in_chunks(net, x, per_rank)
@@ -139,11 +143,13 @@ def sharded_main(args):
             del net
         # ---- c4: augment -> embed, 128 images per rank, descriptors gathered, generator outputs not
         per_rank, side = (2, 32) if dry else (128, 256)
-        x = synth.synth_input(5, (per_rank * world, 3, side, side), 1.0).to(dev)
+        n_glob = args.global_batch if args.global_batch else per_rank * world
+        per_rank = (n_glob + world - 1) // world
+        x = synth.synth_input(5, (n_glob, 3, side, side), 1.0).to(dev)
         chain = _c4_chain(dev)
         dt = timed(lambda: sharding.embed_sharded(chain, x), steps, warmup)
         got = sharding.embed_sharded(chain, x)
-        rec = {"images_per_s": round(per_rank * world / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": per_rank * world,
+        rec = {"images_per_s": round(n_glob / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": n_glob,
                "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
         if dry:
             ref = sharding.descriptors_in_chunks(chain, x, per_rank)
@@ -347,6 +353,7 @@ if __name__ == "__main__":
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--dry-run", action="store_true", help="configs 4 / 5 sharded over N gloo ranks on the CPU, tiny images, bitwise check against one process")
+    ap.add_argument("--global-batch", type=int, default=0, help="sharded configs: images in the global batch (default: 8 / 128 per rank; any N, the ranks need not divide it)")
     ap.add_argument("--sharded", action="store_true", help="run the sharded configs 4 / 5 even with --gpus 1 (one rank: the same code path, RCCL world size 1)")
     a = ap.parse_args()
     if "RANK" in os.environ and (a.gpus > 1 or a.dry_run or a.sharded):

@@ -77,7 +77,8 @@ constexpr int Q_BYTES = HALO_ROWS_PAD * QROWB;             // 20992
 constexpr int STAGE_BYTES = A_BYTES + Q_BYTES;             // 62976
 constexpr int NORM_BYTES = 4096 + 64;                      // (scale, shift): two slots of up to 256 input channels + a zero entry
 constexpr int BM = PH * 16;
-constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES + NORM_BYTES + 4 * 8192;        // + two 4 KB epilogue patches per wave
+// + epilogue patches: two 4 KB patches per wave with four waves (pipelined body), one with eight (all 160 KB are taken then)
+constexpr size_t lds_bytes(int waves) { return 2 * (size_t)STAGE_BYTES + NORM_BYTES + (waves > 4 ? waves * 4096 : 4 * 8192); }
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -108,7 +109,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert((TM == 4 || TM == 8) && (TN == 2 || TN == 4) && TM * TN <= 16, "tile shape (128-row statistics records: one or two per wave)");
+    static_assert((TM == 4 || TM == 8) && (TN == 1 || TN == 2 || TN == 4) && TM * TN <= 16, "tile shape (128-row statistics records: one or two per wave)");
+    constexpr int NWAVES = WGM * WGN;
+    constexpr bool PIPE2 = NWAVES <= 4;             // two epilogue patches per wave
+    // TN == 1 (eight waves of 256 pixels x 32 channels, two per SIMD at 256 registers): an activation fragment feeds ONE MFMA, so the
+    // fragments rotate through a window of AW registers sets, each re-loaded AW MFMAs ahead of its use (TN >= 2: AW = TM, the fragment
+    // of row block i is re-loaded in place for the next substep)
+    constexpr int AW = TN == 1 ? 4 : TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #endif
     constexpr int RING = SHIFT ? 4 : GDT_C_RING;
     static_assert(SLOTS % RING == 0, "ring / buffer positions of a substep must not depend on the chunk");
-    static_assert(TN == 4 || TN == 2, "the weight streams are grouped per 128 output channels");
+    static_assert(TN == 4 || TN == 2 || TN == 1, "the weight streams are grouped per 128 output channels");
     const int wgrp_of_wave = (wn * WTN) >> 7, wblk = ((wn * WTN) >> 5) & 3;      // the wave's 128-column weight group within the tile, its first 32-column block in it
     const int nks = d.Kpad >> 4, nms = d.Kpad >> 5, cin16 = d.Cin >> 4;
     f16x8 b[RING][TN];
@@ -358,10 +365,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) pend[k] = load_piece(cur, 0, 0);      // (placeholder values: overwritten before their first use)
 
-    f16x8 afr[TM];
-    v4i aq[TM];      // (TM == TN: row block j's fragments are fetched behind the MFMAs of column j)
+    f16x8 afr[AW];
+    v4i aq[AW];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
+    for (int i = 0; i < AW; ++i) afr[i] = a_frag(i, 0, 0, 0);
 
     // The four waves run the same code and leave every barrier together, so their vector-memory instructions reach the CU's one address
     // unit in the same cycles and queue behind each other (measured: ~50 cycles of blocked issue per load, three of four waves waiting).
@@ -440,30 +447,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             if (!(GDT_C_ABL & 8) && ct_on(t, j) && s2_on(t))
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i % AW], acc[i][j], 0, 0, 0);     // D[cout][pixel]
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
                         if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i) && s2_on_u(u + RING - 1)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
+                        // the window slot just used takes the fragment AW row blocks on: of this substep (AW < TM) or of the next one
                         if (GDT_C_ABL & 256) {}                                     // (timing only: no fp16 fragment re-loads)
-                        else if (kk < 3) { if (s2_ld(t)) afr[i] = a_frag(i, ty, tx, kk + 1); }
-                        else if (t < NTAP - 1) { if (s2_ld(t + 1)) afr[i] = a_frag(i, nty, ntx, 0); }
+                        else if (i + AW < TM) { if (s2_ld(t)) afr[i % AW] = a_frag(i + AW, ty, tx, kk); }
+                        else if (kk < 3) { if (s2_ld(t)) afr[i % AW] = a_frag(i + AW - TM, ty, tx, kk + 1); }
+                        else if (t < NTAP - 1) { if (s2_ld(t + 1)) afr[i % AW] = a_frag(i + AW - TM, nty, ntx, 0); }
                         if (cu == 0) {             // (the MX weights were last read at the end of substep u - 1; all columns are re-loaded
-                            if (!(GDT_C_ABL & 64) && s2_ld(t)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
+                            if (!(GDT_C_ABL & 64) && i < AW && s2_ld(t)) aq[i] = a_qfrag(i, ty, tx, kk >> 1);      //  behind the first rows: >= 24 MFMAs before their first use)
                             if (!(GDT_C_ABL & (2 | 128)) && 2 * i < TN && s2_ld(t)) {
                                 if (ct_on(t_of(u), 2 * i)) load_bq(2 * i, tn_of(u), ks_of(u));
-                                if (ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
+                                if (2 * i + 1 < TN && ct_on(t_of(u), 2 * i + 1)) load_bq(2 * i + 1, tn_of(u), ks_of(u));
                             }
                         }
                     }
                     if (!(GDT_C_ABL & 2) && cu == 1) {          // the correction product of the 32 k-values just done
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            const v8i av = __builtin_shufflevector(aq[i], aq[i], 0, 1, 2, 3, -1, -1, -1, -1);
+                            const v8i av = __builtin_shufflevector(aq[i % AW], aq[i % AW], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
                                 if (ct_on(t, j) && s2_on(t)) {
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_shufflevector(bq[j], bq[j], 0, 1, 2, 3, 4, 5, -1, -1), av, acc[i][j], 2, 4, 0, bqs[j], 0, a_scale);
                                 }
+                            if (!(GDT_C_ABL & 64) && i + AW < TM && s2_ld(t)) aq[i % AW] = a_qfrag(i + AW, ty, tx, kk >> 1);      // (AW < TM)
                         }
                     }
                     // in-order issue: lay the substep out as MFMA, a few VALU (the halo staging), MFMA, ... with the memory operations
@@ -484,6 +494,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                         for (int m = 0; m < TM * TN; ++m) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            if (AW < TM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                             if ((m & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 flip_stage(STAGE_BYTES - 2 * so);
                 so = STAGE_BYTES - so;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
+                for (int i = 0; i < AW; ++i) afr[i] = a_frag(i, 0, 0, 0);
             }
         };
         if (!S2) {
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         if (!(d.dbg & 4)) {
             float* __restrict__ outp = (float*)d.out;
             const float* __restrict__ resp = (const float*)d.res;
-            float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * 2048;
+            float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * (PIPE2 ? 2048 : 1024);
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));             // (opaque copy: keeps the epilogue's addresses out of the loop's invariant set)
             const int fr_e = lane_e & 31, fh_e = lane_e >> 5, pl = lane_e >> 3, q = lane_e & 7;
@@ -649,7 +660,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
                 const float lo = relu_now ? 0.f : -__builtin_inff();
                 auto put = [&](int blk) {
                     const f32x16& a = acc[blk % TM][blk / TM];
-                    float* pw = patch + (blk & 1) * 1024;
+                    float* pw = patch + (PIPE2 ? (blk & 1) * 1024 : 0);      // (one patch: the wave's LDS operations execute in order, so the next block's writes land behind this block's reads)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         *(float4*)(pw + fr_e * 32 + ((8 * g + 4 * fh_e) ^ wswz)) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int blk = j * TM + i;
-                        const float* pr = patch + (blk & 1) * 1024;
+                        const float* pr = patch + (PIPE2 ? (blk & 1) * 1024 : 0);
                         float4 v[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -752,11 +763,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         flip_stage(STAGE_BYTES - 2 * so);
         so = STAGE_BYTES - so;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) afr[i] = a_frag(i, 0, 0, 0);
+        for (int i = 0; i < AW; ++i) afr[i] = a_frag(i, 0, 0, 0);
     }
 #ifdef GDT_C_STAMP
     if (lane == 0 && d.stamp_out) {
-        unsigned long long* o = d.stamp_out + ((long)blockIdx.x * 4 + wave) * 8;
+        unsigned long long* o = d.stamp_out + ((long)blockIdx.x * NWAVES + wave) * 8;
         o[0] = st_body; o[1] = st_cbar; o[2] = st_tbar; o[3] = st_epi; o[4] = __builtin_amdgcn_s_memtime() - st_begin; o[5] = st_n;
     }
 #endif
@@ -772,10 +783,16 @@ static int c_dbg() { static const int v = [] { const char* e = getenv("GDT_C_DBG
 // with the residual + write-back staging.  (An eight-wave form, two waves of 128 x 64 per SIMD at 256 registers, runs its fp16
 // core faster -- 0.185 vs 0.243 ms -- but pays 0.09 ms for the weight stream and 0.07 for the staging: 0.443 ms complete.)
 // BN_ = 128 (output channel counts that are not a multiple of 256: the 64 -> 128 stride-2 layer): 2 x 2 waves of 128 pixels x 64 channels.
-template <int MODE, int FORM = 0, bool TALL = false, int BN_ = 256>
+// W8 (with TALL): eight waves, two per SIMD at 256 registers each, 1 x 8: every wave owns all 256 pixels x 32 channels.  The same
+// weight bytes per MFMA as 1 x 4 (a weight fragment still feeds 8 MFMAs), twice its LDS fragment bytes (an activation fragment feeds one
+// MFMA); what it buys is a second wave per SIMD: while one waits -- for a weight fragment behind older halo loads (vmcnt retires in
+// order), for an LDS fragment, at the address unit -- the other issues.
+template <int MODE, int FORM = 0, bool TALL = false, int BN_ = 256, bool W8 = false>
 int launch_c(const ConvLaunch& d, hipStream_t stream) {
-    constexpr int BN = BN_, WGM = TALL ? 1 : 2, WGN = TALL ? 4 : 2;
+    constexpr int BN = BN_, WGM = TALL ? 1 : 2, WGN = TALL ? (W8 ? 8 : 4) : 2;
+    constexpr size_t LDS_BYTES = lds_bytes(WGM * WGN);
     static_assert(BN == 256 || (BN == 128 && !TALL), "tile width");
+    static_assert(!W8 || (TALL && FORM == 0), "the eight-wave layout exists for the 3x3 form");
     const int gh = FORM == 2 ? d.OH : d.H, gw = FORM == 2 ? d.OW : d.W;
     const int tiles = d.N * ((gw + 15) / 16) * ((gh + PH - 1) / PH), ntn = d.CoutPad / BN;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -793,19 +810,20 @@ int launch_c(const ConvLaunch& d, hipStream_t stream) {
     static unsigned long long* stamp_buf = nullptr;
     static int stamp_calls = 0;
     ConvLaunch ds = d;
-    if (!stamp_buf) GDT_CHECK_HIP(hipMalloc((void**)&stamp_buf, (size_t)cus * 4 * 8 * sizeof(unsigned long long)));
-    GDT_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)cus * 4 * 8 * sizeof(unsigned long long), stream));
+    constexpr int NWV = WGM * WGN;
+    if (!stamp_buf) GDT_CHECK_HIP(hipMalloc((void**)&stamp_buf, (size_t)cus * NWV * 8 * sizeof(unsigned long long)));
+    GDT_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)cus * NWV * 8 * sizeof(unsigned long long), stream));
     ds.stamp_out = stamp_buf;
     hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, ds, vblocks);
-    if (++stamp_calls % 200 < 20 && WGM * WGN == 4) {          // a few launches per variant of a sustained run
+    if (++stamp_calls % 200 < 20) {          // a few launches per variant of a sustained run
         GDT_CHECK_HIP(hipStreamSynchronize(stream));
-        std::vector<unsigned long long> h((size_t)grid * 4 * 8);
+        std::vector<unsigned long long> h((size_t)grid * NWV * 8);
         GDT_CHECK_HIP(hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double s[6] = {0, 0, 0, 0, 0, 0};
-        for (size_t w = 0; w < (size_t)grid * 4; ++w) for (int k = 0; k < 6; ++k) s[k] += (double)h[w * 8 + k];
-        const double nw = grid * 4.0, nt = s[5] / nw;
-        fprintf(stderr, "[c stamp] MODE %d FORM %d BN %d: tiles/wave %.1f; per tile: chunk bodies %.0f, chunk barriers %.0f, tile barrier %.0f, epilogue %.0f cycles; total per wave %.0f\n",
-                MODE, FORM, BN, nt, s[0] / nw / nt, s[1] / nw / nt, s[2] / nw / nt, s[3] / nw / nt, s[4] / nw);
+        for (size_t w = 0; w < (size_t)grid * NWV; ++w) for (int k = 0; k < 6; ++k) s[k] += (double)h[w * 8 + k];
+        const double nw = grid * (double)NWV, nt = s[5] / nw;
+        fprintf(stderr, "[c stamp] MODE %d FORM %d BN %d waves %d: tiles/wave %.1f; per tile: chunk bodies %.0f, chunk barriers %.0f, tile barrier %.0f, epilogue %.0f cycles; total per wave %.0f\n",
+                MODE, FORM, BN, NWV, nt, s[0] / nw / nt, s[1] / nw / nt, s[2] / nw / nt, s[3] / nw / nt, s[4] / nw);
     }
 #else
     hipLaunchKernelGGL((conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>), dim3(grid), dim3(WGM * WGN * 64), LDS_BYTES, stream, d, vblocks);
@@ -836,16 +854,20 @@ bool gdt_conv_halo_c_eligible(const ConvLaunch& d) {
     return tiles * (d.CoutPad / 256) >= min_tiles && useful >= 0.85;
 }
 
+// few patches (batch 1-4 at 256^2: 16-64 tiles for 256 CUs): 128-column tiles double the number of workgroups
+int gdt_conv_halo_c_columns(const ConvLaunch& d) {
+    static const int narrow_below = [] { const char* e = getenv("GDT_C_NARROW_BELOW"); return e ? atoi(e) : 192; }();
+    const long tiles256 = (long)d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH) * (d.CoutPad / 256);
+    return tiles256 < narrow_below ? 128 : 256;
+}
+
 int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch d = d_in;
     d.dbg = dbg;
     static const int stagger = [] { const char* e = getenv("GDT_C_STAGGER_US"); return e ? atoi(e) : 0; }();
     d.stagger_us = stagger;
-    // few patches (batch 1-4 at 256^2: 16-64 tiles for 256 CUs): 128-column tiles double the number of workgroups
-    static const int narrow_below = [] { const char* e = getenv("GDT_C_NARROW_BELOW"); return e ? atoi(e) : 192; }();
-    const long tiles256 = (long)d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH) * (d.CoutPad / 256);
-    if (tiles256 < narrow_below) {
+    if (gdt_conv_halo_c_columns(d) == 128) {
         if (!d.in_norm) return launch_c<0, 0, false, 128>(d, stream);
         if (d.in_res) {
             if (d.in_out) return launch_c<7, 0, false, 128>(d, stream);
@@ -854,6 +876,15 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
         return d.in_out ? launch_c<5, 0, false, 128>(d, stream) : launch_c<1, 0, false, 128>(d, stream);
     }
     static const int tall = [] { const char* e = getenv("GDT_C_TALL"); return e ? atoi(e) : 1; }();      // 0: the 2 x 2 wave layout
+    static const int waves8 = [] { const char* e = getenv("GDT_C_WAVES"); return e ? atoi(e) == 8 : false; }();      // 8: the 1 x 8 layout, two waves per SIMD
+    if (tall && waves8) {
+        if (!d.in_norm) return launch_c<0, 0, true, 256, true>(d, stream);
+        if (d.in_res) {
+            if (d.in_out) return launch_c<7, 0, true, 256, true>(d, stream);
+            return launch_c<3, 0, true, 256, true>(d, stream);
+        }
+        return d.in_out ? launch_c<5, 0, true, 256, true>(d, stream) : launch_c<1, 0, true, 256, true>(d, stream);
+    }
     if (tall) {
         if (!d.in_norm) return launch_c<0, 0, true>(d, stream);
         if (d.in_res) {

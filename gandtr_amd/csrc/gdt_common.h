@@ -150,6 +150,7 @@ bool gdt_conv_halo_x3_eligible(const ConvLaunch& d);       // conv3x3_halo_x3.hi
 int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_eligible(const ConvLaunch& d);         // conv3x3_halo_c.hip (f16c mode, variant 970256)
 int gdt_launch_conv_halo_c(const ConvLaunch& d, hipStream_t stream);
+int gdt_conv_halo_c_columns(const ConvLaunch& d);           // output-channel columns per tile of the form that launch picks (256, or 128 for few patches)
 bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)

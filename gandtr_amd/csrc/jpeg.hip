@@ -528,6 +528,10 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
     info->scan_offset = r.pos;
     const ScanWalk w = walk_scan(f, n, r.pos, nullptr, 0, nullptr, 0);
     if (w.end_marker >= 0 && w.end_marker != 0xD9) return fail("more than one scan (or a marker inside the scan) -- not decoded on the device");
+    // A scan that runs into the end of the buffer is a truncated file: the reference's loader (pil_loader, datahelpers.py:39-47) raises
+    // OSError "image file is truncated" for it unless every MCU was already decoded, which the host cannot tell without decoding.  Refused:
+    // the caller's host loader (Pillow itself) then raises or tolerates exactly as the reference does.
+    if (w.end_marker < 0) return fail("truncated scan (no EOI marker)");
     if (w.data_bytes >= (1u << 28)) return fail("scan too large");
     const long long total_mcus = (long long)info->mcus_x * info->mcus_y;
     const long long expect = info->restart_interval > 0 ? (total_mcus + info->restart_interval - 1) / info->restart_interval : 1;

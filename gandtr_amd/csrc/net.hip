@@ -132,6 +132,7 @@ struct gdt_net {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     std::vector<double> last_flops;
+    std::vector<double> last_bytes;         // algorithmic HBM bytes per op (op_bytes), merged like last_flops when ops are fused
     std::vector<int> last_variant;          // kernel variant per conv op (see gdt_launch_conv)
 
     size_t blob_append(const void* data, size_t bytes) {
@@ -1217,6 +1218,22 @@ static double op_flops(const gdt_net* net, const Op& o, int n, int rh, int rw) {
     return 0.0;
 }
 
+// Algorithmic HBM bytes of a conv op as its own launch: the input tensor once (a strided 1x1 conv touches only the pixels it samples), the
+// output once, the residual once, the fp16 weights once ("each conv reads its input and writes its output once").  Fused
+// launches subtract the tensors that never exist (see the forward).
+static double op_bytes(const gdt_net* net, const Op& o, int n) {
+    if (o.kind != OP_CONV) return 0.0;
+    const double es = (double)net->esize();
+    const Tensor& ti = net->tensors[o.in];
+    const Tensor& to = net->tensors[o.out];
+    double in_px = (double)n * ti.H * ti.W;
+    if (!o.cd.transposed && o.cd.kh == 1 && o.cd.kw == 1 && o.cd.stride > 1) in_px = (double)n * to.H * to.W;
+    double b = in_px * ti.C * es + (double)n * to.H * to.W * to.C * es;
+    if (o.res >= 0) b += (double)n * to.H * to.W * to.C * es;
+    b += (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw * sizeof(f16);
+    return b;
+}
+
 int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops) {
     GDT_REQUIRE(net && flops, "net");
     Plan plan;
@@ -1256,6 +1273,14 @@ int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int*
     return GDT_OK;
 }
 
+int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, double* bytes) {
+    GDT_REQUIRE(net && bytes, "profile buffers");
+    GDT_REQUIRE(net->last_bytes.size() == net->ops.size(), "no profiled forward has run");
+    GDT_REQUIRE(max_ops >= (int)net->ops.size(), "profile buffers too small");
+    for (size_t i = 0; i < net->ops.size(); ++i) bytes[i] = net->last_bytes[i];
+    return GDT_OK;
+}
+
 int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
                     void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream) {
     GDT_REQUIRE(net && net->finalized, "net must be finalized");
@@ -1280,7 +1305,11 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     if (net->profiling) {
         net->last_flops.resize(net->ops.size());
         net->last_variant.assign(net->ops.size(), 0);
-        for (size_t i = 0; i < net->ops.size(); ++i) net->last_flops[i] = op_flops(net, net->ops[i], n, rh, rw);
+        net->last_bytes.resize(net->ops.size());
+        for (size_t i = 0; i < net->ops.size(); ++i) {
+            net->last_flops[i] = op_flops(net, net->ops[i], n, rh, rw);
+            net->last_bytes[i] = op_bytes(net, net->ops[i], n);
+        }
     }
     for (const Step& stp : plan.steps) {
         const Op& o = net->ops[stp.op];
@@ -1308,6 +1337,12 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     if (net->profiling) {      // the block's FLOPs and time are booked on its first conv
                         net->last_variant[stp.op] = 935000 + oc.cd.cout + (dsf ? 1 : 0);
                         for (int k = 1; k <= (dsf ? 3 : 2); ++k) { net->last_flops[stp.op] += net->last_flops[stp.op + k]; net->last_flops[stp.op + k] = 0.0; }
+                        // bytes: the block-boundary tensors (x once -- it is also the residual --, y once) and every weight matrix once
+                        const double es = (double)net->esize();
+                        double by = (double)n * T[oa.in].H * T[oa.in].W * T[oa.in].C * es + (double)n * T[oc.out].H * T[oc.out].W * T[oc.out].C * es;
+                        for (const Op* w : {&oa, &ob, &oc, od}) if (w) by += (double)w->cd.cin * w->cd.cout * w->cd.kh * w->cd.kw * sizeof(f16);
+                        for (int k = 0; k <= (dsf ? 3 : 2); ++k) net->last_bytes[stp.op + k] = 0.0;
+                        net->last_bytes[stp.op] = by;
                     }
                     break;
                 }
@@ -1342,6 +1377,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     if (net->profiling) {
                         net->last_variant[stp.op] = 946128;
                         net->last_flops[stp.op] += net->last_flops[o.kcat_ds]; net->last_flops[o.kcat_ds] = 0.0;
+                        // bytes: the projected tensor is neither written (projection op) nor read back as the residual (expand op)
+                        const double proj = (double)n * T[o.out].H * T[o.out].W * T[o.out].C * (double)net->esize();
+                        net->last_bytes[stp.op] += net->last_bytes[o.kcat_ds] - 2.0 * proj; net->last_bytes[o.kcat_ds] = 0.0;
                     }
                     break;
                 }
@@ -1417,7 +1455,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         }
                     }
                     if (stp.aug) { d.w_frag2 = (const f16*)(net->dev_blob + ph.w_frag2_off); variant = 955000 + ph.ntaps; rc = gdt_launch_conv_stem_c(d, st); }
-                    else if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970256; rc = gdt_launch_conv_halo_c(d, st); }
+                    else if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970000 + gdt_conv_halo_c_columns(d); rc = gdt_launch_conv_halo_c(d, st); }
                     else rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;

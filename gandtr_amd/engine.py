@@ -166,6 +166,13 @@ class HipNet:
         _hip.check(self.lib.gdt_net_profile_read(self.handle, cap, ctypes.byref(n), kinds, tiles, ms, fl))
         return [(kinds[i], tiles[i], ms[i], fl[i]) for i in range(n.value)]
 
+    def profile_bytes(self):
+        """per-op algorithmic HBM bytes of the last profiled forward (same op order as profile())"""
+        cap = 1024
+        by = (ctypes.c_double * cap)()
+        _hip.check(self.lib.gdt_net_profile_read_bytes(self.handle, cap, by))
+        return [by[i] for i in range(len(self.profile()))]
+
     def workspace_bytes(self, n, rh, rw):
         b = ctypes.c_size_t()
         _hip.check(self.lib.gdt_net_workspace_bytes(self.handle, n, rh, rw, ctypes.byref(b)))

@@ -132,6 +132,10 @@ int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);
  * conv3x3_halo_kernel<BN>), elapsed ms and the algorithmic FLOPs.  No reference counterpart (the reference has wall-clock StopWatch only, mdir/tools/stats.py:48-68). */
 int gdt_net_set_profiling(gdt_net* net, int enable);
 int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int* tile_n, double* ms, double* flops);
+/* ... and the ALGORITHMIC HBM bytes of each op of that forward (conv ops: input once -- a strided 1x1 conv only the pixels it samples --,
+ * output once, residual once, fp16 weights once; a fused launch is booked on its first op without the tensors that never exist):
+ * the numerator of bench.py's HBM view of the Bottleneck 1x1 convs (SURVEY.md section 8d "compulsory bytes"). */
+int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, double* bytes);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Stand-alone descriptor ops (device fp32 buffers)

@@ -60,3 +60,45 @@ def test_sharded_configs_4_and_5_two_ranks_dry_run():
     for key in ("c3_gem_resnet101_ms_hub_default", "c3_gem_resnet101_ms_sms", "c4_augment_then_embed"):
         assert doc[key]["sharded_equals_single_process_bitwise"] is True, key
         assert doc[key]["gathered"] == [2048, 4], key
+
+
+def test_self_launch_four_ranks_dry_run():
+    """world size 4 through bench.py's own launcher (the driver's `--gpus 4` case): the emitted line reports the ranks torch.distributed
+    actually formed"""
+    rc, lines, err = _run(["--gpus", "4", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 4 and doc["rccl_ranks"] == 4 and doc["dry_run"] is True
+
+
+def _configs(args):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_configs.py")] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1200, check=False)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    text = p.stdout.decode()
+    return json.loads(text[text.index("{"):])
+
+
+def test_sharded_configs_4_and_5_four_ranks_ragged_batch_dry_run():
+    """world size 4 with a global batch the ranks do not divide (7 images: chunks 2, 2, 2, 1 -- the last chunk zero-padded for the
+    collective and trimmed after it, SURVEY.md section 8e "Ragged N"): both sharded BASELINE configs, gathered D x 7 on every rank equal
+    to the single-process result over the same chunks bit for bit; `rccl_ranks` is the world size torch.distributed formed."""
+    doc = _configs(["--gpus", "4", "--dry-run", "--global-batch", "7"])
+    assert doc["n_gpus"] == 4 and doc["rccl_ranks"] == 4 and doc["backend"] == "gloo"
+    for key in ("c3_gem_resnet101_ms_hub_default", "c3_gem_resnet101_ms_sms", "c4_augment_then_embed"):
+        assert doc[key]["sharded_equals_single_process_bitwise"] is True, key
+        assert doc[key]["gathered"] == [2048, 7] and doc[key]["global_batch"] == 7, key
+
+
+def test_sharded_configs_two_ranks_empty_last_chunk_dry_run():
+    """3 ranks' worth of work on 2 ranks is ragged; 1 image on 2 ranks leaves the second rank's chunk EMPTY (it learns D from the
+    all-reduce, contributes a zero-padded block and still takes part in the collective)"""
+    doc = _configs(["--gpus", "2", "--dry-run", "--global-batch", "1"])
+    assert doc["rccl_ranks"] == 2
+    for key in ("c3_gem_resnet101_ms_hub_default", "c4_augment_then_embed"):
+        assert doc[key]["sharded_equals_single_process_bitwise"] is True, key
+        assert doc[key]["gathered"] == [2048, 1], key

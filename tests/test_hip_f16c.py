@@ -26,11 +26,13 @@ def _g(seed, name, shape, std=1.0):
     return synth._normal(seed, name, shape, std)
 
 
+@pytest.mark.parametrize("n", [8, 16])
 @pytest.mark.parametrize("norm,res,reflect", [(False, False, True), (False, False, False), (True, False, True), (True, True, True)])
-def test_halo_c_conv3x3(cuda_device, norm, res, reflect):
-    """3x3 / stride 1 conv 256 -> 256 on 8 x 64 x 64 (128 patches: the persistent compensated kernel runs): plain, with the producer's
-    InstanceNorm + ReLU folded into the staging (+ write-back: the normalised tensor is also an output), and with the ResnetBlock form
-    x + IN(conv) folded in.  The statistics of ITS output feed a following InstanceNorm."""
+def test_halo_c_conv3x3(cuda_device, norm, res, reflect, n):
+    """3x3 / stride 1 conv 256 -> 256 on n x 64 x 64: plain, with the producer's InstanceNorm + ReLU folded into the staging (+ write-back:
+    the normalised tensor is also an output), and with the ResnetBlock form x + IN(conv) folded in.  The statistics of ITS output feed a
+    following InstanceNorm.  n = 8: 128 patches, the 128-column form of the persistent compensated kernel; n = 16: 256 patches, the
+    256-column form the batch-64 benchmark runs (gdt_conv_halo_c_columns)."""
     cin = cout = 256
     net = HipNet(cuda_device, "f16c")
     t = net.input(3)
@@ -44,8 +46,11 @@ def test_halo_c_conv3x3(cuda_device, norm, res, reflect):
     o2 = net.instance_norm(out, relu=True)
     taps = [net.output_nchw(out), net.output_nchw(o2)] + ([net.output_nchw(t)] if norm else [])
     net.finalize()
-    x = synth.synth_input(1, (8, 3, 64, 64))
+    x = synth.synth_input(1, (n, 3, 64, 64))
+    net.set_profiling(True)
     outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert (970128 if n == 8 else 970256) in [v for k, v, ms, fl in net.profile() if k == 1]
     a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
     a = a0
     if norm:
@@ -57,6 +62,32 @@ def test_halo_c_conv3x3(cuda_device, norm, res, reflect):
     assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 3e-4
     if norm:
         assert _rel(outs[taps[2]].double().cpu(), a) < 1e-5          # the write-back of the folded normalisation is plain fp32
+
+
+@pytest.mark.parametrize("n", [8, 16])
+def test_halo_c_conv3x3_epilogue_residual(cuda_device, n):
+    """the BatchNorm generator's second ResnetBlock conv (hub hedngan: p2p_networks.py:503-506 with the eval-mode norm folded into the
+    conv): y = x + BN(conv(pad(x))) -- the residual is added in the kernel's EPILOGUE (fetched one block ahead in the pipelined body),
+    128-column form (n = 8) and the 256-column form of the batch-64 benchmark (n = 16), against fp64."""
+    c = 256
+    net = HipNet(cuda_device, "f16c")
+    t = net.input(3)
+    t0 = net.conv(t, _g(0, "w0", (c, 3, 1, 1), 0.7))
+    wt = _g(0, "w", (c, c, 3, 3), 0.05)
+    bn = (1.0 + _g(0, "g", (c,), 0.2), _g(0, "be", (c,), 0.2), _g(0, "m", (c,), 0.3), 0.5 + _g(0, "v", (c,), 0.1).abs())
+    out = net.conv(t0, wt, None, bn=bn, pad=1, reflect=True, residual=t0)
+    tap = net.output_nchw(out)
+    net.finalize()
+    x = synth.synth_input(2, (n, 3, 64, 64))
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert (970128 if n == 8 else 970256) in [v for k, v, ms, fl in net.profile() if k == 1]
+    a0 = F.conv2d(x.double(), _g(0, "w0", (c, 3, 1, 1), 0.7).double())
+    y = F.conv2d(F.pad(a0, (1,) * 4, mode="reflect"), wt.double())
+    g, be, m, v = (q.double() for q in bn)
+    ref = a0 + F.batch_norm(y, m, v, g, be, False, 0.0, 1e-5)
+    assert _rel(outs[tap].double().cpu(), ref) < 2e-4
 
 
 @pytest.mark.parametrize("kind", ["conv3x3", "stride2", "stride2_128", "transposed"])
@@ -93,7 +124,7 @@ def test_halo_c_ragged_patches(cuda_device, kind):
     outs = net.forward(x.to(cuda_device))
     torch.cuda.synchronize()
     variant = [v for k, v, ms, fl in net.profile() if k == 1][-1]
-    assert variant in (970256, 980256, 990256), variant               # a compensated patch kernel ran the layer
+    assert variant in (970256, 970128, 980256, 990256), variant               # a compensated patch kernel ran the layer
     a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
     ref = ref_fn(a0)
     got = outs[tap].double().cpu()

@@ -43,6 +43,30 @@ def test_generator_64x256_batch_independence_and_determinism(cuda_device, precis
         assert err < (3.5e-3 if precision == "f16" else 1e-3), (i, err)
 
 
+def test_hedngan_bn_generator_64x256_against_oracle(cuda_device):
+    """BASELINE config 3's generator as the reference defines it (hub/model.py:139-154: norm_layer = batch, no conv bias) at the BENCHMARKED
+    geometry: batch 64 selects the 256-column form of the compensated patch kernel, whose BatchNorm variant adds the ResnetBlock residual
+    in the pipelined epilogue (p2p_networks.py:505 with the eval-mode norm folded into the conv).  Batches of 2 / 8 (test_hip_models.py)
+    run the 128-column form, so this is the only oracle comparison of the variant the config-3 number is measured on: two images of the
+    64 against O.resnet_generator, north_star's 1e-3 of the pre-tanh range, default precision (f16c)."""
+    from oracle import gandtr_oracle as O
+    sd = synth.generator_state(0, "batch")
+    net = engine.build_generator(sd, cuda_device, pre_tanh=True)
+    assert net.precision == "f16c"
+    x = synth.synth_input(43, (64, 3, 256, 256), 1.0).to(cuda_device)
+    net.set_profiling(True)
+    full = net.forward(x)[net.out_slot]
+    torch.cuda.synchronize()
+    variants = [v for kind, v, _, fl in net.profile() if kind == 1 and fl > 0]
+    net.set_profiling(False)
+    assert variants.count(970256) == 18, variants          # every resblock conv ran conv3x3_halo_c_kernel<256>
+    assert torch.equal(full, net.forward(x)[net.out_slot])
+    for i in (0, 37):
+        ref = O.resnet_generator(x[i:i + 1].cpu(), sd, "batch", 9, pre_tanh=True)
+        err = float((full[i:i + 1].cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-3, (i, err)
+
+
 def test_hedngan_64x256_with_hed(cuda_device):
     gen = engine.build_generator(synth.generator_state(0, "batch"), cuda_device)
     hed = engine.build_hed(synth.hed_state(0), cuda_device, perm=[2, 1, 0], in_affine=([0.5] * 3, [0.09212946, 0.04247542, 0.01890622]))

@@ -102,6 +102,39 @@ def test_golden_files_parse_and_pillow_still_reproduces_them():
             assert np.array_equal(np.asarray(img.convert("RGB")), want), name
 
 
+def test_every_truncation_pillow_refuses_is_refused():
+    """the reference's loader (pil_loader = Image.open(f).convert('RGB'), datahelpers.py:39-47) raises OSError for a file cut inside its
+    scan; the device path must not hand back a zero-padded image for it (datasets.ImagesFromList(ignore_errors=...) and
+    extract_vectors_from_files would embed it): whatever Pillow refuses, gdt_jpeg_parse refuses"""
+    g = _golden()
+    rng = np.random.RandomState(5)
+    blobs = [bytes(g["file_" + str(n)]) for n in g["names"]]
+    blobs.append(_encode(rng.randint(0, 256, (64, 64, 3), dtype=np.uint8), quality=85))
+    pillow_refused = ours_refused = 0
+    for blob in blobs:
+        sos = blob.index(b"\xff\xda")
+        cuts = sorted(set([sos + 14, (sos + len(blob)) // 2, 2 * len(blob) // 3, len(blob) - 40, len(blob) - 3, len(blob) - 2, len(blob) - 1]))
+        for k in cuts:
+            if not sos < k < len(blob):
+                continue
+            cut = blob[:k]
+            try:
+                with Image.open(io.BytesIO(cut)) as img:
+                    img.convert("RGB")
+                pillow_ok = True
+            except OSError:
+                pillow_ok = False
+            try:
+                jpeg.parse(cut)
+                ours_ok = True
+            except ValueError:
+                ours_ok = False
+            pillow_refused += not pillow_ok
+            ours_refused += not ours_ok
+            assert not (ours_ok and not pillow_ok), (len(blob), k)
+    assert pillow_refused > 20 and ours_refused >= pillow_refused
+
+
 def test_parser_survives_truncated_and_corrupted_files():
     """the host parser reads untrusted bytes: every truncation and a few thousand random corruptions of valid files must come back as a
     clean ValueError or as a consistent info (whose scan extraction then stays inside the buffer it was sized for) -- never a crash"""
