@@ -120,6 +120,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Eight waves at 256 registers: nothing that only depends on the lane id may stay live across the chunk loop (the allocator spills it and every
+    // scratch reload is a vector-memory wait behind the halo stream) -- such values are re-made from v_mbcnt where they are used.
+    constexpr bool REMAT = WGM * WGN > 4;
+    auto lane_now = [&]() -> int {
+        if (!REMAT) return lane;
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto tid_now = [&]() -> int { return REMAT ? wave * 64 + lane_now() : tid; };
     const int wm = wave / WGN, wn = wave % WGN;
     const float* __restrict__ inf = (const float*)d.in;
     const float* __restrict__ resf = (const float*)d.in_res;
@@ -156,11 +166,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     const float lo_scale = __builtin_ldexpf(1.f, -d.c_lo_exp), hi_scale = __builtin_ldexpf(1.f, d.c_hi_exp);   // cvt divides by the scale
     struct Pend { float4 r0, r1, s0, s1; unsigned goff; bool ok; };
     auto load_piece = [&](const TileAt& ta, int chunk, int r) -> Pend {
-        int lr = lrow;
+        const int tl = tid_now();
+        int lr = REMAT ? tl >> 3 : lrow;
         asm volatile("" : "+v"(lr));
         const int h = min(r * RPR + lr, HROWS_PAD - 1);
         const int hy = (h * (SHIFT ? 3856 : 3641)) >> 16, hx = h - hy * HW_;
-        const int q = lane & 7;          // a lane always fetches the same 8-channel group of its pixel; the swizzle is applied at the LDS write
+        const int q = tl & 7;          // a lane always fetches the same 8-channel group of its pixel; the swizzle is applied at the LDS write
         int iy = ta.y0 - (CT ? 0 : 1) + hy, ix = ta.x0 - (CT ? 0 : 1) + hx;
         int cbyte = (chunk * 8 + q) * 32;                            // byte offset of this piece's 8 channels within its pixel
         if (S2) {                                                     // virtual channel -> (sub-pixel parity, real channel)
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     float* nlds = (float*)(smem + 2 * STAGE_BYTES);
     auto stage_norm = [&](const TileAt& ta, int slot) {
         const int creal = S2 ? d.Cin >> 2 : d.Cin;
-        for (int i = tid; i < creal / 2; i += NT) {              // float4 = 2 channels x (mean, rstd) -> (scale, shift)
+        for (int i = tid_now(); i < creal / 2; i += NT) {              // float4 = 2 channels x (mean, rstd) -> (scale, shift)
             const float4 v = *(const float4*)(d.in_norm + (long)ta.n * creal * 2 + i * 4);
             *(float4*)(nlds + slot * 512 + i * 4) = make_float4(v.y, -v.x * v.y, v.w, -v.z * v.w);
         }
@@ -196,23 +207,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // (scale, shift) of the lane's 8 channels in the chunk being staged: a lane's channel group is the same for every piece of a chunk,
     // so the factors are fetched from the LDS table once per chunk, not per piece (per piece: four dependent LDS reads, each behind an
     // `s_waitcnt lgkmcnt(0)` that also drained the fragment reads in flight)
+    // (eight waves, 256 registers each: the 16 factor registers are not kept across the chunk -- a piece reads them at its store: six
+    // pieces per chunk and thread, and the partner wave of the SIMD covers the LDS latency)
+    constexpr bool NF_REGS = NWAVES <= 4;
     float4 nf[4];
+    const float4* nf_ptr = nullptr;
     auto load_nf = [&](int slot, int chunk) {
         if (!NORM) return;
-        const int cq = S2 ? ((chunk * 64 + (lane & 7) * 8) & ((1 << (d.lc8 + 1)) - 1)) >> 3 : chunk * 8 + (lane & 7);    // the (real) 8-channel group
+        const int l7 = lane_now() & 7;
+        const int cq = S2 ? ((chunk * 64 + l7 * 8) & ((1 << (d.lc8 + 1)) - 1)) >> 3 : chunk * 8 + l7;    // the (real) 8-channel group
         const float4* np4 = (const float4*)(nlds + slot * 512 + cq * 16);
+        if (NF_REGS) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) nf[k] = np4[k];
+            for (int k = 0; k < 4; ++k) nf[k] = np4[k];
+        } else nf_ptr = np4;
     };
     auto store_piece = [&](int stage_off, int r, const Pend& p) {
-        const int row = min(r * RPR + lrow, HROWS_PAD - 1);
+        const int tl = tid_now();
+        const int row = min(r * RPR + (REMAT ? tl >> 3 : lrow), HROWS_PAD - 1);
         const int phy = (row * (SHIFT ? 3856 : 3641)) >> 16, phx = row - phy * HW_;
         float a[8] = {p.r0.x, p.r0.y, p.r0.z, p.r0.w, p.r1.x, p.r1.y, p.r1.z, p.r1.w};
         if (NORM) {
             const float lo = d.in_relu ? 0.f : -3.0e38f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 v = nf[k];
+                const float4 v = NF_REGS ? nf[k] : nf_ptr[k];
                 a[2 * k] = fmaxf(fmaf(a[2 * k], v.x, v.y), lo);
                 a[2 * k + 1] = fmaxf(fmaf(a[2 * k + 1], v.z, v.w), lo);
             }
@@ -254,10 +273,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
         const f16x8 o = __builtin_bit_cast(f16x8, ov);
-        *(f16x8*)(smem + stage_off + row * ROWB + (((lane & 7) ^ ((phx >> 1) & 7)) << 4)) = o;      // source chunk q at position q ^ key (a_frag)
+        *(f16x8*)(smem + stage_off + row * ROWB + (((tl & 7) ^ ((phx >> 1) & 7)) << 4)) = o;      // source chunk q at position q ^ key (a_frag)
         // fp4 plane: this thread holds source chunk q (channels 8q .. 8q+7): 32-channel block b = q >> 2, dword q & 3;
         // 16-byte position (2b + {lo 0, hi 1}) ^ key, key = conflict-free swizzle of the fragment reads (see a_qfrag)
-        const int q = lane & 7;
+        const int q = tl & 7;
         const int key = SHIFT ? ((phy + 2 * (phx >> 2)) & 3) : ((phx >> 1) & 3);
         const int qo = stage_off + A_BYTES + row * QROWB + ((((q >> 2) << 1) ^ key) << 4) + ((q & 3) << 2);
         *(unsigned*)(smem + qo) = qlo;
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     v6i bq[TN];             // the lane's 32 e2m3 values: the MFMA's 6-register operand tuple, loaded in place (dwordx4 + dwordx2)
     int bqs[TN];            // its E8M0 block scale
     auto lane_bytes = [&](int per_lane) -> unsigned {     // (opaque: keeps the zero-extension next to its load, which is what lets the
-        unsigned v = lane * per_lane;                      //  compiler pick the scalar-base addressing form)
+        unsigned v = lane_now() * per_lane;                //  compiler pick the scalar-base addressing form)
         asm volatile("" : "+v"(v));
         return v;
     };
@@ -447,7 +466,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             if (!(GDT_C_ABL & 8) && ct_on(t, j) && s2_on(t))
+#ifdef GDT_C_SHAPE16_TIMING      // timing only (results are wrong): the same FLOPs, operand loads and accumulator registers on the 16 x 16 x 32 shape
+                            {
+                                typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+                                for (int qq = 0; qq < 2; ++qq) {
+                                    const int q4 = 4 * (2 * (u & 1) + qq);
+                                    f32x4_ tq = {acc[i][j][q4], acc[i][j][q4 + 1], acc[i][j][q4 + 2], acc[i][j][q4 + 3]};
+                                    tq = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u % RING][j], afr[i % AW], tq, 0, 0, 0);
+                                    acc[i][j][q4] = tq[0]; acc[i][j][q4 + 1] = tq[1]; acc[i][j][q4 + 2] = tq[2]; acc[i][j][q4 + 3] = tq[3];
+                                }
+                            }
+#else
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[u % RING][j], afr[i % AW], acc[i][j], 0, 0, 0);     // D[cout][pixel]
+#endif
                         // this row's share of the substep's loads: column i of the ring slot substep u - 1 has finished with, (even
                         // substeps) the fp4 fragment and column i of the MX weights two groups ahead
                         if (!(GDT_C_ABL & 4) && i < TN && ct_on(t_of(u + RING - 1), i) && s2_on_u(u + RING - 1)) load_b((u + RING - 1) % RING, i, tn_of(u + RING - 1), ks_of(u + RING - 1));
@@ -471,7 +503,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
                                 if (ct_on(t, j) && s2_on(t)) {
+#ifdef GDT_C_SHAPE16_TIMING
+                                    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+                                    for (int qq = 0; qq < 2; ++qq) {
+                                        const int q4 = 4 * (2 * ((u >> 1) & 1) + qq);
+                                        f32x4_ tq = {acc[i][j][q4], acc[i][j][q4 + 1], acc[i][j][q4 + 2], acc[i][j][q4 + 3]};
+                                        tq = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(bq[j], bq[j], 0, 1, 2, 3, 4, 5, -1, -1), av, tq, 2, 4, 0, bqs[j], 0, a_scale);
+                                        acc[i][j][q4] = tq[0]; acc[i][j][q4 + 1] = tq[1]; acc[i][j][q4 + 2] = tq[2]; acc[i][j][q4 + 3] = tq[3];
+                                    }
+#else
                                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_shufflevector(bq[j], bq[j], 0, 1, 2, 3, 4, 5, -1, -1), av, acc[i][j], 2, 4, 0, bqs[j], 0, a_scale);
+#endif
                                 }
                             if (!(GDT_C_ABL & 64) && i + AW < TM && s2_ld(t)) aq[i % AW] = a_qfrag(i + AW, ty, tx, kk >> 1);      // (AW < TM)
                         }
@@ -569,7 +612,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
             float* __restrict__ outp = (float*)d.out;
             const float* __restrict__ resp = (const float*)d.res;
             float* patch = (float*)(smem + 2 * STAGE_BYTES + NORM_BYTES) + wave * (PIPE2 ? 2048 : 1024);
-            int lane_e = lane;
+            int lane_e = lane_now();
             asm volatile("" : "+v"(lane_e));             // (opaque copy: keeps the epilogue's addresses out of the loop's invariant set)
             const int fr_e = lane_e & 31, fh_e = lane_e >> 5, pl = lane_e >> 3, q = lane_e & 7;
             const bool relu_now = d.relu != 0;
@@ -867,6 +910,13 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
     d.dbg = dbg;
     static const int stagger = [] { const char* e = getenv("GDT_C_STAGGER_US"); return e ? atoi(e) : 0; }();
     d.stagger_us = stagger;
+#ifdef GDT_C_DEV_W8_ONLY      // dev builds (resource reports, asm): only the eight-wave instantiations are compiled
+    {
+        if (!d.in_norm) return launch_c<0, 0, true, 256, true>(d, stream);
+        if (d.in_res) return d.in_out ? launch_c<7, 0, true, 256, true>(d, stream) : launch_c<3, 0, true, 256, true>(d, stream);
+        return d.in_out ? launch_c<5, 0, true, 256, true>(d, stream) : launch_c<1, 0, true, 256, true>(d, stream);
+    }
+#else
     if (gdt_conv_halo_c_columns(d) == 128) {
         if (!d.in_norm) return launch_c<0, 0, false, 128>(d, stream);
         if (d.in_res) {
@@ -899,6 +949,7 @@ int gdt_launch_conv_halo_c(const ConvLaunch& d_in, hipStream_t stream) {
         return launch_c<3>(d, stream);
     }
     return d.in_out ? launch_c<5>(d, stream) : launch_c<1>(d, stream);
+#endif
 }
 
 // Transposed form (CT): ConvTranspose2d(k3,s2,p1,op1) as one launch (phase_cout > 0, weights of Op::ctf packed by pack_mx), 64 or 128
@@ -920,10 +971,14 @@ bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d) {
 }
 
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d_in, hipStream_t stream) {
+#ifdef GDT_C_DEV_W8_ONLY
+    return GDT_ERR_INVALID;
+#else
     ConvLaunch d = d_in;
     d.dbg = c_dbg();
     if (!d.in_norm) return launch_c<0, 1>(d, stream);
     return d.in_res ? launch_c<3, 1>(d, stream) : launch_c<1, 1>(d, stream);
+#endif
 }
 
 // Stride-2 form (S2): Conv2d(k3, s2, p1, zero padding) over the virtual space-to-depth view of its input.  The launch descriptor carries
@@ -946,6 +1001,9 @@ bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d) {
 }
 
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
+#ifdef GDT_C_DEV_W8_ONLY
+    return GDT_ERR_INVALID;
+#else
     ConvLaunch d = d_in;
     d.dbg = c_dbg();
     if (d.CoutPad % 256 != 0) {
@@ -959,4 +1017,5 @@ int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
     }
     if (!d.in_norm) return launch_c<0, 2>(d, stream);
     return d.in_out ? launch_c<5, 2>(d, stream) : launch_c<1, 2>(d, stream);
+#endif
 }
