@@ -126,6 +126,8 @@ def kernel_name(variant):
         return "conv3x3_halo_c_kernel<256>[stride-2]"
     if variant >= 980000:
         return "conv3x3_halo_c_kernel<256>[transposed]"
+    if variant >= 971000:
+        return "conv3x3_halo_c16_kernel<%d>" % (variant - 971000)     # the same layer on the 16 x 16 MFMA shapes
     if variant >= 970000:
         return "conv3x3_halo_c_kernel<%d>" % (variant - 970000)
     if variant >= 960000:

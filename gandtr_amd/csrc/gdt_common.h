@@ -79,6 +79,11 @@ struct ConvLaunch {
     const f16* w_frag2;           // conv_stem.hip, f16c form: the weight residuals W2 = [w - fp16(w), 0 ..] in the stem fragment order
     const void* w_cfrag;          // fp16 weights grouped per 128 output channels: [CoutPad/128][Kpad/16][4][64 lanes][8 halves] (wmx_* grouped alike)
     const void* wmx_a; const void* wmx_b; const void* wmx_s;
+    // conv3x3_halo_c16.hip (the same layer on the 16 x 16 MFMA shapes): ONE 15 KB record per (64 output channels, 64 k-values), index
+    // (cout / 64) * (Kpad / 64) + k / 64: [fp16 weights of k 0-31: 4 blocks of 16 channels x 64 lanes x 16 B, lane (n, g) = channel block * 16 + n,
+    // k = 8 g ..+7][the same of k 32-63][correction operands, first 16 bytes per lane: 4 blocks x 64 lanes][their last 8 bytes][E8M0 scales: 64 lanes x
+    // 4 blocks]; lane (n, blk) of a correction operand = 32 e2m3 values of fp16(w) (blk 0, 2) / w - fp16(w) (blk 1, 3) of k 0-31 (blk 0, 1) / 32-63 (blk 2, 3)
+    const void* w_c16;
     int c_lo_exp, c_hi_exp;
     int in_f32;                   // conv_head7.hip: `in` is the fp32 NHWC tensor of the f16c mode (rounded to fp16 once, while staging)
     int stagger_us;               // conv3x3_halo_c.hip: start-up delay step between the four workgroup phase groups (0: none)
@@ -151,6 +156,8 @@ int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_eligible(const ConvLaunch& d);         // conv3x3_halo_c.hip (f16c mode, variant 970256)
 int gdt_launch_conv_halo_c(const ConvLaunch& d, hipStream_t stream);
 int gdt_conv_halo_c_columns(const ConvLaunch& d);           // output-channel columns per tile of the form that launch picks (256, or 128 for few patches)
+bool gdt_conv_halo_c16_eligible(const ConvLaunch& d);       // conv3x3_halo_c16.hip (f16c mode on the 16 x 16 MFMA shapes, variant 971256)
+int gdt_launch_conv_halo_c16(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)

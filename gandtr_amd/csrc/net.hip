@@ -34,6 +34,7 @@ struct PackedPhase {
     size_t w_frag2_off = 0; bool has_aug = false;   // f16c stem: w_frag = augmented W1, w_frag2 = residual W2 (conv_stem.hip)
     size_t w_pair_off = 0; bool has_pair = false;   // fp16 ResNet stem (7x7 s2): pair-word k order of conv_stem_pair_kernel
     size_t wc_off = 0, wmx_a_off = 0, wmx_b_off = 0, wmx_s_off = 0; bool has_mx = false;   // f16c mode: block-scaled correction operands (ConvLaunch::wmx_*)
+    size_t w16_off = 0; bool has_mx16 = false;   // ... in the 16 x 16 fragment order, one record per (64 channels, 64 k) (ConvLaunch::w_c16)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
 };
@@ -677,6 +678,52 @@ void pack_mx(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<u
             }
 }
 
+// The same operands in the fragment order of the 16 x 16 MFMA shapes (conv3x3_halo_c16.hip), grouped per 64 output channels (a wave's slice):
+//   wc   index = ((group * K/32 + step) * 4 + block) * 64 + lane: lane (n = lane & 15, g = lane >> 4) = fp16(w[group * 64 + block * 16 + n][32 step + 8 g .. +7])
+//   a/b index = ((group * K/64 + m) * 4 + block) * 64 + lane, sc index = ((group * K/64 + m) * 64 + lane) * 4 + block: lane (n, blk = lane >> 4) = 32 e2m3 values (+ E8M0 scale) of the 32 k-values
+//   64 m + 32 (blk >> 1) .. +31: fp16(w) for blk 0 / 2, w - fp16(w) for blk 1 / 3 -- the K blocks of v_mfma_scale_f32_16x16x128_f8f6f4, which meet
+//   the activation row [a_lo | a_hi | a_lo' | a_hi'] block by block.
+void pack_mx16(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector<unsigned char>& a, std::vector<unsigned char>& b,
+               std::vector<unsigned>& sc, std::vector<f16>& wc) {
+    const int ng = cout_pad / 64, nks = Kpad / 32, nms = Kpad / 64;
+    a.assign((size_t)ng * nms * 4 * 64 * 16, 0); b.assign((size_t)ng * nms * 4 * 64 * 8, 0); sc.assign((size_t)ng * nms * 4 * 64, 0);
+    wc.assign((size_t)cout_pad * Kpad, (f16)0.f);
+    for (int g = 0; g < ng; ++g)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int cb = 0; cb < 4; ++cb)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const float* src = wf.data() + (size_t)(g * 64 + cb * 16 + (ln & 15)) * Kpad + ks * 32 + (ln >> 4) * 8;
+                    f16* dst = wc.data() + ((((size_t)g * nks + ks) * 4 + cb) * 64 + ln) * 8;
+                    for (int e = 0; e < 8; ++e) dst[e] = (f16)src[e];
+                }
+    for (int g = 0; g < ng; ++g)
+        for (int ms = 0; ms < nms; ++ms)
+            for (int cb = 0; cb < 4; ++cb)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int blk = ln >> 4;
+                    const float* src = wf.data() + (size_t)(g * 64 + cb * 16 + (ln & 15)) * Kpad + ms * 64 + (blk >> 1) * 32;
+                    float v[32], mx = 0.f;
+                    for (int i = 0; i < 32; ++i) {
+                        const float hi = (float)(f16)src[i];
+                        v[i] = (blk & 1) ? src[i] - hi : hi;
+                        mx = std::max(mx, std::fabs(v[i]));
+                    }
+                    int e = 0;
+                    if (mx > 0.f) { e = (int)std::ceil(std::log2(mx / 7.5f)); if (std::ldexp(mx, -e) > 7.5f) ++e; }
+                    e = std::min(std::max(e, -126), 127);
+                    unsigned char bytes[24] = {0};
+                    for (int i = 0; i < 32; ++i) {
+                        const unsigned code = (unsigned)quant_e2m3(std::ldexp(v[i], -e));
+                        const int bit = 6 * i;
+                        bytes[bit >> 3] |= (unsigned char)(code << (bit & 7));
+                        if ((bit & 7) > 2) bytes[(bit >> 3) + 1] |= (unsigned char)(code >> (8 - (bit & 7)));
+                    }
+                    const size_t fi = (((size_t)g * nms + ms) * 4 + cb) * 64 + ln;
+                    memcpy(a.data() + fi * 16, bytes, 16); memcpy(b.data() + fi * 8, bytes + 16, 8);
+                    sc[(((size_t)g * nms + ms) * 64 + ln) * 4 + cb] = (unsigned)(127 + e);      // (a lane's four block scales side by side: one dwordx4)
+                }
+}
+
 void fold_bn(const gdt_conv_desc& cd, const float* bias, const float* g, const float* b, const float* m, const float* v,
              std::vector<float>& scale, std::vector<float>& shift, bool& has_shift) {
     scale.assign(cd.cout, 1.f); shift.assign(cd.cout, 0.f);
@@ -805,6 +852,22 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             ph.wmx_b_off = net->blob_append(mb.data(), mb.size());
             ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
             ph.has_mx = true;
+            if (cd.kh == 3 && cd.kw == 3 && cd.stride == 1 && !cd.transposed && ph.ntaps == 9 && o.cout_pad % 256 == 0) {   // conv3x3_halo_c16.hip
+                pack_mx16(wf, o.cout_pad, ph.Kpad, ma, mb, msc, wc);
+                // one record per (64 output channels, 64 k-values): [fp16 step 0][fp16 step 1][16-byte parts][8-byte parts][scales] = 15 KB, so that
+                // a wave's weight stream is ONE sequential region (conv3x3_halo_c16.hip)
+                const size_t nrec = (size_t)(o.cout_pad / 64) * (ph.Kpad / 64);
+                std::vector<unsigned char> rec(nrec * 15360);
+                for (size_t r = 0; r < nrec; ++r) {
+                    unsigned char* dst = rec.data() + r * 15360;
+                    memcpy(dst, (const unsigned char*)wc.data() + r * 8192, 8192);
+                    memcpy(dst + 8192, ma.data() + r * 4096, 4096);
+                    memcpy(dst + 12288, mb.data() + r * 2048, 2048);
+                    memcpy(dst + 14336, (const unsigned char*)msc.data() + r * 1024, 1024);
+                }
+                ph.w16_off = net->blob_append(rec.data(), rec.size());
+                ph.has_mx16 = true;
+            }
         }
         if (!net->precision && cin_pad % 64 == 0 && o.cout_pad % 32 == 0) {      // conv3x3_halo_rb.hip / conv_igemm_rb.hip
             // fragment order: lane = fh * 32 + fr holds cout = cb * 32 + fr, k = ks * 16 + fh * 8 + e
@@ -1440,6 +1503,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.w_cfrag = net->dev_blob + ph.wc_off; d.wmx_a = net->dev_blob + ph.wmx_a_off; d.wmx_b = net->dev_blob + ph.wmx_b_off; d.wmx_s = net->dev_blob + ph.wmx_s_off;
                         d.c_lo_exp = 12; d.c_hi_exp = 0;
                     }
+                    if (ph.has_mx16) {
+                        d.w_c16 = net->dev_blob + ph.w16_off;
+                    }
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
@@ -1455,6 +1521,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         }
                     }
                     if (stp.aug) { d.w_frag2 = (const f16*)(net->dev_blob + ph.w_frag2_off); variant = 955000 + ph.ntaps; rc = gdt_launch_conv_stem_c(d, st); }
+                    else if (net->precision == 2 && gdt_conv_halo_c16_eligible(d)) { variant = 971256; rc = gdt_launch_conv_halo_c16(d, st); }
                     else if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970000 + gdt_conv_halo_c_columns(d); rc = gdt_launch_conv_halo_c(d, st); }
                     else rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;

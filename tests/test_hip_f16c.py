@@ -50,7 +50,8 @@ def test_halo_c_conv3x3(cuda_device, norm, res, reflect, n):
     net.set_profiling(True)
     outs = net.forward(x.to(cuda_device))
     torch.cuda.synchronize()
-    assert (970128 if n == 8 else 970256) in [v for k, v, ms, fl in net.profile() if k == 1]
+    ran = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert (970128 in ran) if n == 8 else (971256 in ran or 970256 in ran)      # (971256: conv3x3_halo_c16.hip, GDT_CONV_HALO_C16=0 switches it off)
     a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
     a = a0
     if norm:
@@ -82,7 +83,8 @@ def test_halo_c_conv3x3_epilogue_residual(cuda_device, n):
     net.set_profiling(True)
     outs = net.forward(x.to(cuda_device))
     torch.cuda.synchronize()
-    assert (970128 if n == 8 else 970256) in [v for k, v, ms, fl in net.profile() if k == 1]
+    ran = [v for k, v, ms, fl in net.profile() if k == 1]
+    assert (970128 in ran) if n == 8 else (971256 in ran or 970256 in ran)
     a0 = F.conv2d(x.double(), _g(0, "w0", (c, 3, 1, 1), 0.7).double())
     y = F.conv2d(F.pad(a0, (1,) * 4, mode="reflect"), wt.double())
     g, be, m, v = (q.double() for q in bn)
