@@ -160,6 +160,8 @@ bool gdt_conv_halo_c16_eligible(const ConvLaunch& d);       // conv3x3_halo_c16.
 int gdt_launch_conv_halo_c16(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_ct_c16_eligible(const ConvLaunch& d);         // conv_ct_c16.hip: the transposed form on the 16 x 16 MFMA shapes (variant 981256)
+int gdt_launch_conv_ct_c16(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d, hipStream_t stream);
 bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W);   // conv_bneck.hip: Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut) as one launch (variant 935000 + C)

@@ -724,6 +724,22 @@ void pack_mx16(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector
                 }
 }
 
+// the 15 KB records of conv3x3_halo_c16.hip / conv_ct_c16.hip from a [cols][Kpad] fp32 matrix (cols % 64 == 0, Kpad % 64 == 0)
+std::vector<unsigned char> pack_records16(const std::vector<float>& wf, int cols, int Kpad) {
+    std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
+    pack_mx16(wf, cols, Kpad, ma, mb, msc, wc);
+    const size_t nrec = (size_t)(cols / 64) * (Kpad / 64);
+    std::vector<unsigned char> rec(nrec * 15360);
+    for (size_t r = 0; r < nrec; ++r) {
+        unsigned char* dst = rec.data() + r * 15360;
+        memcpy(dst, (const unsigned char*)wc.data() + r * 8192, 8192);
+        memcpy(dst + 8192, ma.data() + r * 4096, 4096);
+        memcpy(dst + 12288, mb.data() + r * 2048, 2048);
+        memcpy(dst + 14336, (const unsigned char*)msc.data() + r * 1024, 1024);
+    }
+    return rec;
+}
+
 void fold_bn(const gdt_conv_desc& cd, const float* bias, const float* g, const float* b, const float* m, const float* v,
              std::vector<float>& scale, std::vector<float>& shift, bool& has_shift) {
     scale.assign(cd.cout, 1.f); shift.assign(cd.cout, 0.f);
@@ -853,18 +869,9 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             ph.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
             ph.has_mx = true;
             if (cd.kh == 3 && cd.kw == 3 && cd.stride == 1 && !cd.transposed && ph.ntaps == 9 && o.cout_pad % 256 == 0) {   // conv3x3_halo_c16.hip
-                pack_mx16(wf, o.cout_pad, ph.Kpad, ma, mb, msc, wc);
                 // one record per (64 output channels, 64 k-values): [fp16 step 0][fp16 step 1][16-byte parts][8-byte parts][scales] = 15 KB, so that
                 // a wave's weight stream is ONE sequential region (conv3x3_halo_c16.hip)
-                const size_t nrec = (size_t)(o.cout_pad / 64) * (ph.Kpad / 64);
-                std::vector<unsigned char> rec(nrec * 15360);
-                for (size_t r = 0; r < nrec; ++r) {
-                    unsigned char* dst = rec.data() + r * 15360;
-                    memcpy(dst, (const unsigned char*)wc.data() + r * 8192, 8192);
-                    memcpy(dst + 8192, ma.data() + r * 4096, 4096);
-                    memcpy(dst + 12288, mb.data() + r * 2048, 2048);
-                    memcpy(dst + 14336, (const unsigned char*)msc.data() + r * 1024, 1024);
-                }
+                const std::vector<unsigned char> rec = pack_records16(wf, o.cout_pad, ph.Kpad);
                 ph.w16_off = net->blob_append(rec.data(), rec.size());
                 ph.has_mx16 = true;
             }
@@ -1075,6 +1082,23 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 cf.wmx_b_off = net->blob_append(mb.data(), mb.size());
                 cf.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
                 cf.has_mx = true;
+                if (cd.cout % 16 == 0) {      // conv_ct_c16.hip: column = (cout / 16) * 64 + phase * 16 + cout % 16 -- a wave's four 16-column blocks are the four phases
+                    std::vector<float> w16((size_t)ncol * cf.Kpad, 0.f);
+                    for (int col = 0; col < ncol; ++col) {
+                        const int phase = (col >> 4) & 3, co = (col >> 6) * 16 + (col & 15);
+                        const int py = phase >> 1, px = phase & 1;
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+                                if (ky < 0 || kx < 0) continue;
+                                for (int c = 0; c < cd.cin; ++c)
+                                    w16[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] = weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co];
+                            }
+                    }
+                    const std::vector<unsigned char> rec = pack_records16(w16, ncol, cf.Kpad);
+                    cf.w16_off = net->blob_append(rec.data(), rec.size());
+                    cf.has_mx16 = true;
+                }
             }
             std::vector<f16> pf(net->precision ? 0 : pk.size());
             for (int cb = 0; cb < (net->precision ? 0 : ncol / 32); ++cb)
@@ -1470,6 +1494,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.w_cfrag = net->dev_blob + o.ctf.wc_off; d.wmx_a = net->dev_blob + o.ctf.wmx_a_off; d.wmx_b = net->dev_blob + o.ctf.wmx_b_off; d.wmx_s = net->dev_blob + o.ctf.wmx_s_off;
                         d.c_lo_exp = 12; d.c_hi_exp = 0;
                         variant = 980256;
+                        if (o.ctf.has_mx16) d.w_c16 = net->dev_blob + o.ctf.w16_off;
+                        if (gdt_conv_ct_c16_eligible(d)) { variant = 981256; rc = gdt_launch_conv_ct_c16(d, st); }
+                        else
                         rc = gdt_launch_conv_halo_c_ct(d, st);
                     } else
                     rc = gdt_conv_halo_ct_eligible(d) ? gdt_launch_conv_halo_ct(d, st) : gdt_launch_conv_igemm_rb(d, st, &variant);
