@@ -74,6 +74,8 @@ SIGNATURES = {
     "gdt_retrieval_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_retrieval_scores_ranks": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                            c_void_p]),
+    "gdt_retrieval_select_negatives": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                               c_int, c_int, c_void_p]),
     "gdt_l2n_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "gdt_gem_l2n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gdt_mfma_only_tflops": (c_int, [c_int, POINTER(c_double), c_void_p]),

@@ -66,6 +66,47 @@ int plan(int ndb, int nq, int d, bool ranks, Layout& L) {
     return GDT_OK;
 }
 
+
+// Cluster-aware hard-negative selection (mdir/external/cirtorch/datasets/traindataset.py:256-275): per query walk its ranked pool from the
+// best score down and take the first `nnum` images that belong neither to the query's cluster nor to the cluster of an image already taken;
+// the statistic of the reference, ||q - p + 1e-6||_2 per chosen negative, is evaluated by the whole wave.  One wave per query: lane 0 walks
+// (a dependent chain of two small loads per step), all lanes compute the distances.
+__global__ __launch_bounds__(64) void select_negatives_kernel(const int* __restrict__ ranks_t, const int* __restrict__ pool_cluster,
+                                                              const int* __restrict__ query_cluster, const float* __restrict__ vecs,
+                                                              const float* __restrict__ qvecs, int* __restrict__ neg_pos, float* __restrict__ neg_dist,
+                                                              int* __restrict__ status, int ndb, int nq, int d, int nnum, int index_base) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    __shared__ int chosen[64];
+    if (lane == 0) {
+        int used[65];
+        int nused = 1, n = 0;
+        used[0] = query_cluster[q];
+        const int* rk = ranks_t + (size_t)q * ndb;
+        for (int r = 0; r < ndb && n < nnum; ++r) {
+            const int p = rk[r] - index_base;
+            const int c = pool_cluster[p];
+            bool seen = false;
+            for (int k = 0; k < nused; ++k) seen |= used[k] == c;
+            if (!seen) { chosen[n++] = p; used[nused++] = c; }
+        }
+        for (int k = n; k < nnum; ++k) chosen[k] = -1;
+        if (n < nnum) atomicOr(status, 1);          // the pool ran out of clusters: the reference's loop would index past the ranks
+    }
+    __syncthreads();
+    for (int k = 0; k < nnum; ++k) {
+        const int p = chosen[k];
+        float acc = 0.f;
+        if (p >= 0)
+            for (int i = lane; i < d; i += 64) {
+                const float df = qvecs[(size_t)q * d + i] - vecs[(size_t)p * d + i] + 1e-6f;
+                acc += df * df;
+            }
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) { neg_pos[(size_t)q * nnum + k] = p < 0 ? -1 : p + index_base; neg_dist[(size_t)q * nnum + k] = p < 0 ? 0.f : sqrtf(acc); }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,6 +162,18 @@ int gdt_retrieval_scores_ranks(const float* vecs, const float* qvecs, float* sco
     GDT_CHECK_HIP(rocprim::segmented_radix_sort_pairs_desc((void*)(ws + L.tmp), tb, (const float*)scores_t, (float*)(ws + L.keys),
                                                             (const int*)idx, ranks_t, (unsigned)((size_t)nq * ndb), (unsigned)nq,
                                                             (const int*)offs, (const int*)(offs + 1), 0, 32, st));
+    return GDT_OK;
+}
+
+int gdt_retrieval_select_negatives(const int* ranks_t, const int* pool_cluster, const int* query_cluster, const float* vecs, const float* qvecs,
+                                   int* neg_pos, float* neg_dist, int* status, int ndb, int nq, int d, int nnum, int index_base, void* stream) {
+    GDT_REQUIRE(ranks_t && pool_cluster && query_cluster && vecs && qvecs && neg_pos && neg_dist && status, "null buffer");
+    GDT_REQUIRE(ndb >= 1 && nq >= 1 && d >= 1 && nnum >= 1 && nnum <= 64, "1 <= nnum <= 64 negatives per query");
+    hipStream_t st = (hipStream_t)stream;
+    GDT_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    hipLaunchKernelGGL(select_negatives_kernel, dim3(nq), dim3(64), 0, st, ranks_t, pool_cluster, query_cluster, vecs, qvecs, neg_pos, neg_dist, status,
+                       ndb, nq, d, nnum, index_base);
+    GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 

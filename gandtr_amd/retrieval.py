@@ -40,6 +40,46 @@ def scores_and_ranks(vecs, qvecs, with_ranks=True, index_base=0):
     return scores_t.t(), (ranks_t.t() if with_ranks else None)
 
 
+def select_negatives(ranks, pool_clusters, query_clusters, vecs, qvecs, nnum, index_base=0):
+    """The selection loop of the reference's hard-negative mining on the device (traindataset.py:256-275): per query (column of ``ranks``,
+    Ndb x Nq as returned by ``scores_and_ranks``) the first ``nnum`` pool positions whose cluster is neither the query's nor that of a
+    position already taken.  pool_clusters: Ndb ints, query_clusters: Nq ints.  Returns (positions Nq x nnum int32, distances Nq x nnum fp32 =
+    ||q - p + 1e-6||_2, the reference's statistic).  Raises IndexError where the reference's ``ranks[r, q]`` would run past the pool."""
+    lib = _hip.load()
+    dev = vecs.device
+    v, q = _rows(vecs), _rows(qvecs)
+    ndb, d = v.shape
+    nq = q.shape[0]
+    rk = ranks.t().contiguous().to(torch.int32)                               # [Nq][Ndb]
+    pc = torch.as_tensor(pool_clusters, dtype=torch.int32, device=dev).contiguous()
+    qc = torch.as_tensor(query_clusters, dtype=torch.int32, device=dev).contiguous()
+    if rk.shape != (nq, ndb) or pc.numel() != ndb or qc.numel() != nq:
+        raise ValueError("ranks is Ndb x Nq, pool_clusters has Ndb and query_clusters Nq entries")
+    pos = torch.empty((nq, nnum), dtype=torch.int32, device=dev)
+    dist_ = torch.empty((nq, nnum), dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.gdt_retrieval_select_negatives(rk.data_ptr(), pc.data_ptr(), qc.data_ptr(), v.data_ptr(), q.data_ptr(), pos.data_ptr(),
+                                                      dist_.data_ptr(), status.data_ptr(), ndb, nq, d, int(nnum), int(index_base),
+                                                      torch.cuda.current_stream(dev).cuda_stream))
+    if int(status.item()) & 1:
+        raise IndexError("hard-negative selection ran past the pool: fewer than %d other clusters among its images" % nnum)
+    return pos, dist_
+
+
+def search_hard_negatives(qidxs, qvecs, idxs2images, poolvecs, clusters, nnum):
+    """``TuplesDataset._search_hard_negatives`` (traindataset.py:246-279) with scores, sort AND the cluster-aware selection on the device.
+    qidxs: image index per query; qvecs: D x Nq; idxs2images: image index per pool position; poolvecs: D x Npool; clusters: cluster id per image
+    index (``self.clusters``); nnum negatives per query.  Returns what the reference returns: (nidxs -- a list of nnum image indices per query --,
+    {"average_negative_distance": [one l2 distance per chosen negative, query by query]})."""
+    clusters = torch.as_tensor(clusters)
+    idxs2images_t = torch.as_tensor(idxs2images, dtype=torch.int64)
+    _, ranks = scores_and_ranks(poolvecs, qvecs)
+    pos, dist_ = select_negatives(ranks, clusters[idxs2images_t], clusters[torch.as_tensor(qidxs, dtype=torch.int64)], poolvecs, qvecs, nnum)
+    nidxs = idxs2images_t[pos.cpu().long()].tolist()
+    return nidxs, {"average_negative_distance": dist_.cpu().reshape(-1).tolist()}
+
+
 def sharded_topk(vecs_local, qvecs, k, group=None):
     """Database sharded over the ranks of one node (contiguous chunks, as gandtr_amd.sharding), queries replicated.
     Every rank scores its shard, keeps its local top-k per query and all-gathers the candidates (k scores + k global ids per

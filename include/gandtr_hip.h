@@ -173,6 +173,15 @@ int gdt_l2n_rows(const float* x, float* y, int n, int d, float eps, void* stream
 int gdt_retrieval_workspace_bytes(int ndb, int nq, int d, int with_ranks, size_t* bytes);
 int gdt_retrieval_scores_ranks(const float* vecs, const float* qvecs, float* scores_t, int* ranks_t, int ndb, int nq, int d,
                                int index_base, void* workspace, size_t workspace_bytes, void* stream);
+/* Cluster-aware hard-negative selection on the ranks above -- replaces the Python loop of
+ *   TuplesDataset._search_hard_negatives   mdir/external/cirtorch/datasets/traindataset.py:256-275
+ * ranks_t [nq][ndb] as written by gdt_retrieval_scores_ranks (pool positions + index_base, best score first), pool_cluster [ndb] / query_cluster [nq]:
+ * the cluster id of every pool image / query (self.clusters[...]).  Per query the first `nnum` pool images (1 <= nnum <= 64) whose cluster is neither
+ * the query's nor that of an image already taken: neg_pos [nq][nnum] (pool positions + index_base, -1 where the pool ran out of clusters: *status
+ * then has bit 0 set -- the reference's loop would raise IndexError), neg_dist [nq][nnum] = ||q - p + 1e-6||_2, the reference's statistic.
+ * vecs [ndb][d], qvecs [nq][d] fp32 rows; every pointer is a device buffer. */
+int gdt_retrieval_select_negatives(const int* ranks_t, const int* pool_cluster, const int* query_cluster, const float* vecs, const float* qvecs,
+                                   int* neg_pos, float* neg_dist, int* status, int ndb, int nq, int d, int nnum, int index_base, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * CLAHE post-processing ("next" row of SURVEY.md section 8f, rank 1: the step between generator and embedder)

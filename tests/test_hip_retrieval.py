@@ -49,3 +49,31 @@ def test_invalid_arguments(cuda_device):
         retrieval.scores_and_ranks(torch.zeros(100, 10, device=cuda_device), torch.zeros(100, 2, device=cuda_device))   # D not a power of two
     with pytest.raises(ValueError):
         retrieval.scores_and_ranks(torch.zeros(128, 10, device=cuda_device), torch.zeros(64, 2, device=cuda_device))
+
+
+@pytest.mark.parametrize("d,npool,nq,nclusters,nnum", [(512, 3000, 40, 200, 5), (2048, 20000, 70, 1500, 5), (128, 400, 9, 12, 10)])
+def test_hard_negative_selection_matches_reference_loop(cuda_device, d, npool, nq, nclusters, nnum):
+    """``TuplesDataset._search_hard_negatives`` (traindataset.py:246-279) on the device -- mm + sort + the cluster-aware selection -- against the
+    CPU restatement of the reference loop run on the DEVICE's ranking (ties in fp32 scores may order differently on two machines; the selection
+    itself is integer bookkeeping and must agree exactly), distances to 1e-5"""
+    from oracle import retrieval_oracle as R
+    rng = np.random.RandomState(d + nq)
+    nimg = npool + 500
+    poolvecs, qvecs = _unit(3, d, npool), _unit(4, d, nq)
+    clusters = rng.randint(0, nclusters, nimg).tolist()
+    idxs2images = rng.permutation(nimg)[:npool].tolist()
+    qidxs = rng.randint(0, nimg, nq).tolist()
+    nidxs, stats = retrieval.search_hard_negatives(qidxs, qvecs.to(cuda_device), idxs2images, poolvecs.to(cuda_device), clusters, nnum)
+    _, ranks = retrieval.scores_and_ranks(poolvecs.to(cuda_device), qvecs.to(cuda_device))
+    want, wdist = R.search_hard_negatives(qidxs, qvecs.numpy(), idxs2images, poolvecs.numpy(), clusters, nnum, ranks=ranks.cpu().numpy())
+    assert nidxs == want
+    assert np.allclose(stats["average_negative_distance"], wdist, atol=1e-5)
+    for q, row in enumerate(nidxs):                                      # the rules themselves
+        cl = [clusters[i] for i in row]
+        assert len(set(cl)) == nnum and clusters[qidxs[q]] not in cl
+
+
+def test_hard_negative_selection_runs_out_of_clusters(cuda_device):
+    poolvecs, qvecs = _unit(5, 64, 50), _unit(6, 64, 3)
+    with pytest.raises(IndexError):
+        retrieval.search_hard_negatives([0, 1, 2], qvecs.to(cuda_device), list(range(10, 60)), poolvecs.to(cuda_device), [0, 1, 2] * 20, 5)
