@@ -32,7 +32,7 @@ class JpegInfo(ctypes.Structure):
                 ("td", c_int * 3), ("ta", c_int * 3), ("restart_interval", c_int), ("mcus_x", c_int), ("mcus_y", c_int),
                 ("blocks_per_mcu", c_int), ("nsegments", c_int), ("scan_offset", ctypes.c_ulonglong),
                 ("scan_capacity", ctypes.c_ulonglong), ("quant", (ctypes.c_ushort * 64) * 4), ("huff_bits", (ctypes.c_ubyte * 17) * 4),
-                ("huff_vals", (ctypes.c_ubyte * 256) * 4)]
+                ("huff_vals", (ctypes.c_ubyte * 256) * 4), ("progressive", c_int), ("comp_id", c_int * 3)]
 
 
 class JpegItem(ctypes.Structure):
@@ -92,6 +92,11 @@ SIGNATURES = {
                                             POINTER(ctypes.c_uint), POINTER(c_size_t), c_int]),
     "gdt_jpeg_decode_workspace_bytes": (c_int, [POINTER(JpegItem), c_int, POINTER(c_size_t)]),
     "gdt_jpeg_decode_u8_batch": (c_int, [POINTER(JpegItem), c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "gdt_jpeg_progressive_coefficients": (c_int, [c_char_p, c_size_t, POINTER(JpegInfo), c_void_p]),
+    "gdt_jpeg_progressive_coefficients_batch": (c_int, [POINTER(c_void_p), POINTER(c_size_t), POINTER(JpegInfo), c_int, c_void_p, POINTER(c_size_t),
+                                                        POINTER(c_int), c_int]),
+    "gdt_jpeg_decode_coef_workspace_bytes": (c_int, [POINTER(JpegInfo), c_int, POINTER(c_size_t)]),
+    "gdt_jpeg_decode_coef_u8_batch": (c_int, [POINTER(JpegInfo), c_void_p, POINTER(c_size_t), POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     "gdt_whiten_learn_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_whiten_learn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int),
                                  c_void_p, c_size_t, c_void_p]),

@@ -439,8 +439,9 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
         const int len = r.u16();
         if (len < 2 || !r.has((size_t)len - 2)) return fail("truncated segment");
         const size_t end = r.pos + len - 2;
-        if (m == 0xC0 || m == 0xC1) {
+        if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             if (have_frame) return fail("more than one frame");
+            info->progressive = m == 0xC2;
             if (len < 8) return fail("bad frame header");
             const int prec = r.u8();
             info->height = r.u16(); info->width = r.u16(); info->ncomp = r.u8();
@@ -455,8 +456,6 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
                 if (info->tq[c] > 3) return fail("bad quantisation table number");
             }
             have_frame = true;
-        } else if (m == 0xC2) {
-            return fail("progressive files are not decoded on the device");
         } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return fail("lossless / hierarchical / arithmetic-coded files are not decoded on the device");
         } else if (m == 0xCC) {
@@ -465,7 +464,15 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
             while (r.pos < end) {
                 if (end - r.pos < 17) return fail("bad Huffman table");
                 const int tc_th = r.u8(), tc = tc_th >> 4, th = tc_th & 15;
-                if (tc > 1 || th > 1) return fail("Huffman table numbers above 1 (not baseline)");
+                if (tc > 1 || th > 3) return fail("bad Huffman table number");
+                if (th > 1) {                  // tables 2 / 3: progressive files only (their coefficient decoder reads the tables itself)
+                    if (!info->progressive && have_frame) return fail("Huffman table numbers above 1 (not baseline)");
+                    int total = 0;
+                    for (int l = 1; l <= 16; ++l) total += r.u8();
+                    if (total > 256 || end - r.pos < (size_t)total) return fail("bad Huffman table");
+                    r.pos += total;
+                    continue;
+                }
                 const int idx = tc * 2 + th;
                 int total = 0;
                 info->huff_bits[idx][0] = 0;
@@ -489,6 +496,12 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
             if (len >= 7 && memcmp(f + r.pos, "JFIF", 5) == 0) jfif = true;
         } else if (m == 0xEE) {
             if (len >= 14 && memcmp(f + r.pos, "Adobe", 5) == 0) { adobe = true; adobe_transform = f[r.pos + 11]; }
+        } else if (m == 0xDA && info->progressive) {
+            if (!have_frame) return fail("scan before the frame header");
+            for (int c = 0; c < info->ncomp; ++c)
+                if (!have_q[info->tq[c]]) return fail("frame refers to a quantisation table that was not defined");
+            r.pos -= 4;                        // the coefficient decoder starts at this SOS marker (tables may change between the scans)
+            break;
         } else if (m == 0xDA) {
             if (!have_frame) return fail("scan before the frame header");
             if (len < 6 + 2) return fail("bad scan header");
@@ -526,6 +539,11 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
     info->blocks_per_mcu = info->ncomp == 1 ? 1 : hmax * vmax + 2;
     if ((long long)info->mcus_x * info->mcus_y * info->blocks_per_mcu >= (1LL << 26)) return fail("image too large");
     info->scan_offset = r.pos;
+    if (info->progressive) {                  // (the scans are walked -- and a truncated file refused -- by gdt_jpeg_progressive_coefficients)
+        for (int c = 0; c < 3; ++c) info->comp_id[c] = comp_id[c];
+        info->nsegments = 1; info->scan_capacity = scan_capacity_for(0);
+        return GDT_OK;
+    }
     const ScanWalk w = walk_scan(f, n, r.pos, nullptr, 0, nullptr, 0);
     if (w.end_marker >= 0 && w.end_marker != 0xD9) return fail("more than one scan (or a marker inside the scan) -- not decoded on the device");
     // A scan that runs into the end of the buffer is a truncated file: the reference's loader (pil_loader, datahelpers.py:39-47) raises
@@ -581,6 +599,7 @@ int make_plan(const gdt_jpeg_item* items, int n, int mode, Plan& p) {
         const gdt_jpeg_info& f = *it.info;
         GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3) && f.width > 0 && f.height > 0 && f.nsegments >= 1 && f.mcus_x > 0 && f.mcus_y > 0,
                     "jpeg: info was not filled by gdt_jpeg_parse");
+        GDT_REQUIRE(!f.progressive, "jpeg: progressive files are decoded through gdt_jpeg_progressive_coefficients + gdt_jpeg_decode_coef_u8_batch");
         GDT_REQUIRE(((uintptr_t)it.scan & 15) == 0, "jpeg: scan buffers must be 16-byte aligned");
         DImg& d = p.imgs[i];
         memset(&d, 0, sizeof(d));
@@ -689,6 +708,272 @@ int run_decode(const gdt_jpeg_item* items, int n, int mode, const Plan& p, char*
     return GDT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ host: progressive files (ITU T.81 Annex G)
+// A progressive file codes every coefficient in several scans: a band of the zigzag sequence (spectral selection Ss..Se) at a time, and within a
+// band first the high bits (successive approximation: "first" scans code value >> Al) and then one more bit per "refinement" scan.  The scans refine
+// the same coefficient array one after the other, so this is a sequential pass over the file: it runs on the host and hands the device the finished
+// coefficients (gdt_jpeg_decode_coef_u8_batch).  Procedures restated from the standard: G.1.2 (DC first: F.2.2.1 on the point-transformed value;
+// DC refinement: one bit per block; AC first: run / size symbols with end-of-band runs EOBn; AC refinement: correction bits for the coefficients that are
+// already non-zero, new coefficients of magnitude 1 placed after r ZERO-HISTORY positions).
+struct HuffHost {
+    int maxcode[18], valptr[17], mincode[17];
+    unsigned char vals[256];
+    unsigned short look[512];                     // 9-bit prefix -> (length << 8 | symbol), 0 = longer code
+    bool defined = false;
+    void build(const unsigned char* bits /* [17] */, const unsigned char* v) {
+        memcpy(vals, v, 256);
+        memset(look, 0, sizeof(look));
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valptr[l] = k; mincode[l] = code;
+            for (int i = 0; i < bits[l]; ++i, ++code, ++k)
+                if (l <= 9) for (int f = 0; f < (1 << (9 - l)); ++f) look[(code << (9 - l)) | f] = (unsigned short)((l << 8) | v[k]);
+            maxcode[l] = bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        defined = true;
+    }
+};
+
+struct BitReader {
+    const unsigned char* f; size_t n, pos;
+    unsigned long long acc = 0; int cnt = 0;
+    int marker = -1;                              // a marker was met: zeros are fed from here on
+    bool starved = false;                         // ... or the buffer ended
+    void fill() {
+        while (cnt <= 56) {
+            unsigned b = 0;
+            if (marker < 0 && pos < n) {
+                b = f[pos++];
+                if (b == 0xFF) {
+                    size_t q = pos;
+                    while (q < n && f[q] == 0xFF) ++q;
+                    if (q >= n) { starved = true; pos = n; b = 0; }
+                    else if (f[q] == 0x00) pos = q + 1;                        // stuffed byte
+                    else { marker = f[q]; pos = q + 1; b = 0; }
+                }
+            } else if (marker < 0) starved = true;
+            acc |= (unsigned long long)b << (56 - cnt);
+            cnt += 8;
+        }
+    }
+    unsigned peek(int k) { if (cnt < k) fill(); return (unsigned)(acc >> (64 - k)); }
+    void skip(int k) { acc <<= k; cnt -= k; }
+    unsigned bits(int k) { if (k == 0) return 0; const unsigned v = peek(k); skip(k); return v; }
+    int decode(const HuffHost& h) {
+        const unsigned p = peek(16);
+        const unsigned short e = h.look[p >> 7];
+        if (e) { skip(e >> 8); return e & 255; }
+        int code = (int)(p >> 6), l = 10;
+        while (l <= 16 && code > h.maxcode[l]) { ++l; code = (int)(p >> (16 - l)); }
+        if (l > 16) { skip(16); return 0; }       // corrupt stream: a zero symbol keeps the walk bounded
+        skip(l);
+        return h.vals[(h.valptr[l] + code - h.mincode[l]) & 255];
+    }
+    // restart: drop the rest of the current byte; the RSTn marker has been (or is about to be) consumed
+    void restart() {
+        acc = 0; cnt = 0;
+        if (marker < 0) {                         // the marker lies ahead (the interval ended exactly on a byte boundary and nothing was pre-fetched past it)
+            size_t q = pos;
+            while (q + 1 < n && !(f[q] == 0xFF && f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7)) {
+                if (f[q] == 0xFF && f[q + 1] != 0x00 && f[q + 1] != 0xFF) break;
+                ++q;
+            }
+            if (q + 1 < n && f[q] == 0xFF && f[q + 1] >= 0xD0 && f[q + 1] <= 0xD7) pos = q + 2;
+        } else if (marker >= 0xD0 && marker <= 0xD7) marker = -1;
+    }
+};
+inline int extend(unsigned v, int s) { return s == 0 ? 0 : ((int)v < (1 << (s - 1)) ? (int)v - (1 << s) + 1 : (int)v); }
+
+int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info, short* coef) {
+    if (!info.progressive || info.scan_offset < 2 || info.scan_offset >= n) return fail("info was not filled by gdt_jpeg_parse for a progressive file");
+    const int ncomp = info.ncomp, B = info.blocks_per_mcu;
+    const int hmax = ncomp == 3 ? info.hs[0] : 1, vmax = ncomp == 3 ? info.vs[0] : 1;
+    const long long total_blocks = (long long)info.mcus_x * info.mcus_y * B;
+    memset(coef, 0, (size_t)total_blocks * 64 * sizeof(short));
+    const int nY = ncomp == 1 ? 1 : hmax * vmax;
+    // the block grid a NON-interleaved scan of component c covers (its own size, not padded to whole MCUs) and its block -> storage index
+    auto comp_w = [&](int c) { const int hs = (ncomp == 3 && c == 0) ? hmax : 1; return ((info.width * hs + hmax - 1) / hmax + 7) / 8; };
+    auto comp_h = [&](int c) { const int vs = (ncomp == 3 && c == 0) ? vmax : 1; return ((info.height * vs + vmax - 1) / vmax + 7) / 8; };
+    auto block_at = [&](int c, int bx, int by) -> short* {
+        long long g;
+        if (ncomp == 3 && c == 0) g = ((long long)(by / vmax) * info.mcus_x + bx / hmax) * B + (by % vmax) * hmax + (bx % hmax);
+        else if (ncomp == 3) g = ((long long)by * info.mcus_x + bx) * B + nY + (c - 1);
+        else g = (long long)by * info.mcus_x + bx;
+        return coef + g * 64;
+    };
+    HuffHost dc[4], ac[4];
+    for (int t = 0; t < 2; ++t) {                 // tables 0 / 1 as the headers before the first scan left them
+        int any = 0;
+        for (int l = 1; l <= 16; ++l) any += info.huff_bits[t][l];
+        if (any) dc[t].build(info.huff_bits[t], info.huff_vals[t]);
+        any = 0;
+        for (int l = 1; l <= 16; ++l) any += info.huff_bits[2 + t][l];
+        if (any) ac[t].build(info.huff_bits[2 + t], info.huff_vals[2 + t]);
+    }
+    int restart_interval = info.restart_interval;
+    // tables 2 / 3 defined BEFORE the first scan were skipped by the header parser: re-read every DHT of the file up to the first scan
+    {
+        size_t pos = 2;
+        while (pos + 4 <= info.scan_offset) {
+            if (f[pos] != 0xFF) break;
+            const int m = f[pos + 1];
+            if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0xFF) { pos += (m == 0xFF) ? 1 : 2; continue; }
+            const size_t len = ((size_t)f[pos + 2] << 8) | f[pos + 3];
+            if (len < 2 || pos + 2 + len > n) break;
+            if (m == 0xC4) {
+                size_t q = pos + 4; const size_t end = pos + 2 + len;
+                while (q + 17 <= end) {
+                    const int tc = f[q] >> 4, th = f[q] & 15;
+                    int total = 0; unsigned char bits[17] = {0}, vals[256] = {0};
+                    for (int l = 1; l <= 16; ++l) { bits[l] = f[q + l]; total += bits[l]; }
+                    if (total > 256 || q + 17 + total > end || tc > 1 || th > 3) break;
+                    memcpy(vals, f + q + 17, total);
+                    (tc ? ac[th] : dc[th]).build(bits, vals);
+                    q += 17 + total;
+                }
+            }
+            pos += 2 + len;
+        }
+    }
+    size_t pos = info.scan_offset;
+    bool saw_eoi = false;
+    int scans = 0;
+    while (pos + 2 <= n) {
+        if (f[pos] != 0xFF) return fail("progressive: marker expected between the scans");
+        int m = f[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD9) { saw_eoi = true; break; }
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) break;
+        const size_t len = ((size_t)f[pos] << 8) | f[pos + 1];
+        if (len < 2 || pos + len > n) return fail("progressive: truncated segment");
+        const size_t end = pos + len;
+        if (m == 0xC4) {
+            size_t q = pos + 2;
+            while (q < end) {
+                if (end - q < 17) return fail("bad Huffman table");
+                const int tc = f[q] >> 4, th = f[q] & 15;
+                int total = 0; unsigned char bits[17] = {0}, vals[256] = {0};
+                for (int l = 1; l <= 16; ++l) { bits[l] = f[q + l]; total += bits[l]; }
+                if (tc > 1 || th > 3 || total > 256 || end - q - 17 < (size_t)total) return fail("bad Huffman table");
+                memcpy(vals, f + q + 17, total);
+                (tc ? ac[th] : dc[th]).build(bits, vals);
+                q += 17 + total;
+            }
+            pos = end; continue;
+        }
+        if (m == 0xDD) { if (len != 4) return fail("bad restart interval"); restart_interval = (f[pos + 2] << 8) | f[pos + 3]; pos = end; continue; }
+        if (m == 0xDB) return fail("progressive: quantisation tables redefined between the scans are not supported");
+        if (m != 0xDA) { pos = end; continue; }    // (APPn / COM between scans)
+        // ---- one scan
+        if (len < 8) return fail("bad scan header");
+        const int ns = f[pos + 2];
+        if (ns < 1 || ns > ncomp || len != (size_t)(6 + 2 * ns)) return fail("bad scan header");
+        int sc[3], td[3], ta[3];
+        for (int i = 0; i < ns; ++i) {
+            const int id = f[pos + 3 + 2 * i], tt = f[pos + 4 + 2 * i];
+            int c = -1;
+            for (int k = 0; k < ncomp; ++k) if (info.comp_id[k] == id) c = k;
+            if (c < 0 || (i > 0 && c <= sc[i - 1])) return fail("progressive: scan names an unknown component (or components out of order)");
+            sc[i] = c; td[i] = tt >> 4; ta[i] = tt & 15;
+            if (td[i] > 3 || ta[i] > 3) return fail("bad Huffman table number");
+        }
+        const int Ss = f[pos + 3 + 2 * ns], Se = f[pos + 4 + 2 * ns], Ah = f[pos + 5 + 2 * ns] >> 4, Al = f[pos + 5 + 2 * ns] & 15;
+        if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1))
+            return fail("progressive: bad spectral selection / successive approximation parameters");
+        for (int i = 0; i < ns; ++i) {
+            if (Ss == 0 && Ah == 0 && !dc[td[i]].defined) return fail("scan refers to a Huffman table that was not defined");
+            if (Ss > 0 && !ac[ta[i]].defined) return fail("scan refers to a Huffman table that was not defined");
+        }
+        BitReader br{f, n, end};
+        ++scans;
+        const bool interleaved = ns > 1;
+        // geometry of the scan: MCUs of the frame (interleaved) or the component's own blocks
+        const int sw = interleaved ? info.mcus_x : comp_w(sc[0]), sh = interleaved ? info.mcus_y : comp_h(sc[0]);
+        const long long units = (long long)sw * sh;
+        int pred[3] = {0, 0, 0};
+        unsigned eobrun = 0;
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        long long until_restart = restart_interval > 0 ? restart_interval : -1;
+        for (long long u = 0; u < units; ++u) {
+            if (until_restart == 0) {
+                br.restart();
+                pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+                until_restart = restart_interval;
+            }
+            if (until_restart > 0) --until_restart;
+            const int ux = (int)(u % sw), uy = (int)(u / sw);
+            for (int i = 0; i < ns; ++i) {
+                const int c = sc[i];
+                const int bw = interleaved && ncomp == 3 && c == 0 ? hmax : 1, bh = interleaved && ncomp == 3 && c == 0 ? vmax : 1;
+                for (int by = 0; by < bh; ++by)
+                    for (int bx = 0; bx < bw; ++bx) {
+                        short* blk = interleaved ? block_at(c, ux * bw + bx, uy * bh + by) : block_at(c, ux, uy);
+                        if (Ss == 0) {
+                            if (Ah == 0) {                        // DC, first scan
+                                const int ssz = br.decode(dc[td[i]]) & 15;
+                                pred[c] += extend(br.bits(ssz), ssz);
+                                blk[0] = (short)(pred[c] * (1 << Al));
+                            } else if (br.bits(1)) blk[0] = (short)(blk[0] | p1);     // DC refinement
+                        } else if (Ah == 0) {                     // AC band, first scan
+                            if (eobrun > 0) { --eobrun; continue; }
+                            for (int k = Ss; k <= Se; ++k) {
+                                const int rs = br.decode(ac[ta[i]]), r = rs >> 4, sz = rs & 15;
+                                if (sz) {
+                                    k += r;
+                                    if (k > 63) break;
+                                    blk[h_nat[k]] = (short)(extend(br.bits(sz), sz) * (1 << Al));
+                                } else if (r == 15) k += 15;
+                                else { eobrun = (1u << r) + (r ? br.bits(r) : 0u) - 1u; break; }
+                            }
+                        } else {                                  // AC band, refinement
+                            int k = Ss;
+                            if (eobrun == 0) {
+                                for (; k <= Se; ++k) {
+                                    const int rs = br.decode(ac[ta[i]]);
+                                    int r = rs >> 4, sz = rs & 15, val = 0;
+                                    if (sz) val = br.bits(1) ? p1 : m1;              // (sz is 1: a new coefficient of magnitude 1 << Al)
+                                    else if (r != 15) { eobrun = (1u << r) + (r ? br.bits(r) : 0u); break; }
+                                    // skip r coefficients whose history is zero; the non-zero ones on the way take a correction bit each
+                                    for (; k <= Se; ++k) {
+                                        short& cf = blk[h_nat[k]];
+                                        if (cf != 0) {
+                                            if (br.bits(1) && (cf & p1) == 0) cf = (short)(cf + (cf >= 0 ? p1 : m1));
+                                        } else if (--r < 0) break;
+                                    }
+                                    if (val && k <= 63) blk[h_nat[k]] = (short)val;
+                                }
+                            }
+                            if (eobrun > 0) {                     // the rest of the band: correction bits only
+                                for (; k <= Se; ++k) {
+                                    short& cf = blk[h_nat[k]];
+                                    if (cf != 0 && br.bits(1) && (cf & p1) == 0) cf = (short)(cf + (cf >= 0 ? p1 : m1));
+                                }
+                                --eobrun;
+                            }
+                        }
+                    }
+            }
+        }
+        if (br.starved) return fail("truncated scan (the file ends inside a progressive scan)");
+        // the scan's end: the marker the reader ran into, or the next marker in the file
+        if (br.marker >= 0) pos = br.pos - 2;
+        else {
+            size_t q = br.pos;
+            while (q + 1 < n && !(f[q] == 0xFF && f[q + 1] != 0x00 && f[q + 1] != 0xFF)) ++q;
+            pos = q;
+        }
+        while (pos + 1 < n && f[pos] == 0xFF && f[pos + 1] >= 0xD0 && f[pos + 1] <= 0xD7) pos += 2;      // (a stray restart marker at the end of a scan)
+    }
+    if (!saw_eoi) return fail("truncated file (no EOI marker)");
+    if (scans == 0) return fail("no scan");
+    return GDT_OK;
+}
+
 // the two host steps for a LIST of files on a few threads (they are independent per file and memory-bound; one call instead of 2n also spares a
 // scripting host its per-call overhead)
 template <typename F>
@@ -714,6 +999,7 @@ int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info
 int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off) {
     GDT_REQUIRE(file != nullptr && info != nullptr && dst != nullptr && seg_off != nullptr, "jpeg: null argument");
     GDT_REQUIRE(info->scan_offset > 0 && info->scan_offset <= nbytes && info->nsegments >= 1, "jpeg: info was not filled by gdt_jpeg_parse");
+    GDT_REQUIRE(!info->progressive, "jpeg: a progressive file has no single scan to extract (gdt_jpeg_progressive_coefficients)");
     const ScanWalk w = walk_scan(file, nbytes, info->scan_offset, dst, info->scan_capacity - 16, seg_off, info->nsegments - 1);
     GDT_REQUIRE(!w.overflow && w.restarts + 1 == info->nsegments && scan_capacity_for(w.data_bytes) == info->scan_capacity,
                 "jpeg: the file does not match the info");
@@ -757,6 +1043,86 @@ int gdt_jpeg_decode_u8_batch(const gdt_jpeg_item* items, int n, int mode, void* 
     if (workspace_bytes < p.total) { gdt_set_error("jpeg: workspace too small"); return GDT_ERR_WORKSPACE; }
     char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
     return run_decode(items, n, mode, p, ws, (hipStream_t)stream);
+}
+
+int gdt_jpeg_progressive_coefficients(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, short* coef) {
+    GDT_REQUIRE(file != nullptr && info != nullptr && coef != nullptr, "jpeg: null argument");
+    GDT_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->mcus_x > 0 && info->mcus_y > 0 && info->blocks_per_mcu >= 1, "jpeg: info was not filled by gdt_jpeg_parse");
+    return progressive_impl(file, nbytes, *info, coef);
+}
+
+int gdt_jpeg_progressive_coefficients_batch(const unsigned char* const* files, const size_t* nbytes, const gdt_jpeg_info* infos, int n, short* coef,
+                                            const size_t* coef_off, int* status, int threads) {
+    GDT_REQUIRE(files != nullptr && nbytes != nullptr && infos != nullptr && coef != nullptr && coef_off != nullptr && status != nullptr && n >= 0, "jpeg: null argument");
+    for_each_file(n, threads, [&](int i) { status[i] = files[i] ? gdt_jpeg_progressive_coefficients(files[i], nbytes[i], &infos[i], coef + coef_off[i]) : GDT_ERR_INVALID; });
+    return GDT_OK;
+}
+
+static int plan_coef(const gdt_jpeg_info* infos, int n, const size_t* coef_off, unsigned char* const* dst, Plan& p) {
+    GDT_REQUIRE(infos != nullptr && n >= 1 && n <= 65535, "jpeg: 1..65535 images per call");
+    p.imgs.resize(n); p.tabs.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const gdt_jpeg_info& f = infos[i];
+        GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3) && f.width > 0 && f.height > 0 && f.mcus_x > 0 && f.mcus_y > 0 && f.blocks_per_mcu >= 1,
+                    "jpeg: info was not filled by gdt_jpeg_parse");
+        DImg& d = p.imgs[i];
+        memset(&d, 0, sizeof(d));
+        d.width = f.width; d.height = f.height; d.ncomp = f.ncomp; d.B = f.blocks_per_mcu;
+        d.mcus_x = f.mcus_x; d.mcus_y = f.mcus_y; d.hs0 = f.ncomp == 3 ? f.hs[0] : 1; d.vs0 = f.ncomp == 3 ? f.vs[0] : 1;
+        d.total_blocks = (unsigned)((long long)f.mcus_x * f.mcus_y * f.blocks_per_mcu);
+        d.coef_off = coef_off ? coef_off[i] : 0;
+        for (int c = 0; c < f.ncomp; ++c) {
+            const int hs = c == 0 ? d.hs0 : 1, vs = c == 0 ? d.vs0 : 1;
+            d.pitch[c] = f.mcus_x * hs * 8;
+            d.dw[c] = (f.width * hs + d.hs0 - 1) / d.hs0;
+            d.dh[c] = (f.height * vs + d.vs0 - 1) / d.vs0;
+            d.plane_off[c] = p.plane_bytes;
+            p.plane_bytes += ((size_t)d.pitch[c] * f.mcus_y * vs * 8 + 15) / 16 * 16;
+            memcpy(p.tabs[i].quant[c], f.quant[f.tq[c]], 128);
+        }
+        d.dst = dst ? dst[i] : nullptr;
+        p.max_blocks = std::max(p.max_blocks, d.total_blocks);
+        p.max_pixels = std::max(p.max_pixels, (unsigned)f.width * (unsigned)f.height);
+        GDT_REQUIRE((long long)f.width * f.height < (1LL << 31), "jpeg: image too large");
+    }
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + ALIGN - 1) / ALIGN * ALIGN; return at; };
+    p.off_imgs = take(p.imgs.size() * sizeof(DImg));
+    p.off_tabs = take(p.tabs.size() * sizeof(DTab));
+    p.off_planes = take(p.plane_bytes);
+    p.total = o + ALIGN;
+    return GDT_OK;
+}
+
+int gdt_jpeg_decode_coef_workspace_bytes(const gdt_jpeg_info* infos, int n, size_t* bytes) {
+    GDT_REQUIRE(bytes != nullptr, "bytes");
+    Plan p;
+    const int rc = plan_coef(infos, n, nullptr, nullptr, p);
+    if (rc != GDT_OK) return rc;
+    *bytes = p.total;
+    return GDT_OK;
+}
+
+int gdt_jpeg_decode_coef_u8_batch(const gdt_jpeg_info* infos, const short* coef_dev, const size_t* coef_off, unsigned char* const* dst_hwc, int n,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    GDT_REQUIRE(coef_dev != nullptr && coef_off != nullptr && dst_hwc != nullptr && workspace != nullptr, "jpeg: null argument");
+    Plan p;
+    const int rc = plan_coef(infos, n, coef_off, dst_hwc, p);
+    if (rc != GDT_OK) return rc;
+    for (int i = 0; i < n; ++i) GDT_REQUIRE(dst_hwc[i] != nullptr, "jpeg: null output buffer");
+    if (workspace_bytes < p.total) { gdt_set_error("jpeg: workspace too small"); return GDT_ERR_WORKSPACE; }
+    char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
+    hipStream_t st = (hipStream_t)stream;
+    DImg* d_imgs = (DImg*)(ws + p.off_imgs);
+    DTab* d_tabs = (DTab*)(ws + p.off_tabs);
+    unsigned char* d_planes = (unsigned char*)(ws + p.off_planes);
+    GDT_CHECK_HIP(hipMemcpyAsync(d_imgs, p.imgs.data(), p.imgs.size() * sizeof(DImg), hipMemcpyHostToDevice, st));
+    GDT_CHECK_HIP(hipMemcpyAsync(d_tabs, p.tabs.data(), p.tabs.size() * sizeof(DTab), hipMemcpyHostToDevice, st));
+    GDT_CHECK_HIP(hipStreamSynchronize(st));                    // (the staging vectors live in this frame only)
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((p.max_blocks + 63u) / 64u, n), dim3(64), 0, st, d_imgs, d_tabs, coef_dev, d_planes);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((p.max_pixels + 255u) / 256u, n), dim3(256), 0, st, d_imgs, d_planes);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
 }
 
 }  // extern "C"

@@ -6,8 +6,11 @@ uploaded and decoded by HIP launches (gandtr_amd/csrc/jpeg.hip): Huffman decodin
 dequantisation + inverse DCT, chroma upsampling and colour conversion -- bit-identical to Pillow / libjpeg-turbo.  The host parses the
 headers and strips the byte stuffing from the entropy-coded segment while staging it for the upload; it decodes nothing.
 
-Baseline files only (8-bit, Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0).  ``parse`` raises ValueError for
-anything else, with the reason; ``load_many`` passes that on unless the caller supplies its own loader for such files."""
+Baseline files (8-bit, Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0) are decoded on the device end to end.
+Progressive files (SOF2: their scans refine the same coefficients several times over, a sequential pass per scan) have their coefficients
+decoded by the library on a few host threads and go through the device for everything behind the entropy decoder -- same arithmetic, same
+bytes.  ``parse`` raises ValueError for anything else (arithmetic coding, CMYK, 12-bit, ...), with the reason; ``load_many`` passes that on
+unless the caller supplies its own loader for such files."""
 import ctypes
 import os
 
@@ -82,10 +85,47 @@ def _staging(nbytes):
     return _stage[:nbytes]
 
 
+def _decode_progressive(parsed, device):
+    """progressive files: coefficients by the library's host decoder (one call, a few threads), one upload, device back end"""
+    lib = _hip.load()
+    n = len(parsed)
+    offs, total = [], 0
+    for p in parsed:
+        offs.append(total)
+        total += p.info.mcus_x * p.info.mcus_y * p.info.blocks_per_mcu * 64
+    coef = torch.empty(total, dtype=torch.int16).pin_memory()
+    infos = (_hip.JpegInfo * n)(*[p.info for p in parsed])
+    files, keep = _ptr_array([p.data for p in parsed])
+    status = (ctypes.c_int * n)()
+    coef_off = (ctypes.c_size_t * n)(*offs)
+    _hip.check(lib.gdt_jpeg_progressive_coefficients_batch(files, (ctypes.c_size_t * n)(*[len(p.data) for p in parsed]), infos, n, coef.data_ptr(),
+                                                           coef_off, status, _THREADS))
+    for i in range(n):
+        if status[i] != _hip.GDT_OK:            # raise with the reason
+            _hip.check(lib.gdt_jpeg_progressive_coefficients(parsed[i].data, len(parsed[i].data), ctypes.byref(infos[i]), coef.data_ptr() + 2 * offs[i]))
+            raise ValueError("JPEG file %d of the list was refused" % i)
+    with torch.cuda.device(device):
+        coef_dev = coef.to(device, non_blocking=True)
+        out_offs, out_total = [], 0
+        for p in parsed:
+            out_offs.append(out_total)
+            out_total += (p.info.width * p.info.height * 3 + 255) // 256 * 256
+        out = torch.empty(out_total, dtype=torch.uint8, device=device)
+        dst = (ctypes.c_void_p * n)(*[out.data_ptr() + oo for oo in out_offs])
+        nbytes = ctypes.c_size_t()
+        _hip.check(lib.gdt_jpeg_decode_coef_workspace_bytes(infos, n, ctypes.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        _hip.check(lib.gdt_jpeg_decode_coef_u8_batch(infos, coef_dev.data_ptr(), coef_off, dst, n, ws.data_ptr(), nbytes.value,
+                                                     torch.cuda.current_stream().cuda_stream))
+        torch.cuda.current_stream().synchronize()      # (the pinned coefficient buffer is released with this frame)
+    return [out[oo:oo + p.info.width * p.info.height * 3].view(p.info.height, p.info.width, 3) for p, oo in zip(parsed, out_offs)]
+
+
 def decode_many(blobs, device=None, sequential=False):
-    """Decodes a list of baseline JPEG files (bytes, or ``Parsed``) in one library call.  Returns uint8 H x W x 3 tensors on the device,
-    equal to ``np.asarray(Image.open(f).convert('RGB'))``.  ``sequential`` selects the one-thread-per-restart-interval entropy decoder
-    (the checker of the parallel one)."""
+    """Decodes a list of JPEG files (bytes, or ``Parsed``) in one library call per kind (baseline / progressive).  Returns uint8 H x W x 3
+    tensors on the device, equal to ``np.asarray(Image.open(f).convert('RGB'))``.  ``sequential`` selects the one-thread-per-restart-interval
+    entropy decoder of the baseline path (the checker of the parallel one).  The call synchronises the stream (pinned staging buffers; the
+    repair rounds of the parallel entropy decoder read a flag) and is not capturable into a hipGraph."""
     lib = _hip.load()
     if not blobs:
         return []
@@ -96,6 +136,16 @@ def decode_many(blobs, device=None, sequential=False):
     parsed = list(blobs)
     for i, p in zip(raw, parse_many([blobs[i] for i in raw])):
         parsed[i] = p
+    prog = [i for i, p in enumerate(parsed) if p.info.progressive]
+    if prog:
+        out = [None] * len(parsed)
+        for i, t in zip(prog, _decode_progressive([parsed[i] for i in prog], device)):
+            out[i] = t
+        base = [i for i in range(len(parsed)) if not parsed[i].info.progressive]
+        if base:
+            for i, t in zip(base, decode_many([parsed[i] for i in base], device, sequential)):
+                out[i] = t
+        return out
     n = len(parsed)
     # staging: every image's un-stuffed scan at a 16-byte aligned offset of ONE pinned buffer -> one upload
     offs, total, seg_index, nseg = [], 0, [], 0
@@ -146,8 +196,8 @@ def _read(source):
 
 def load_many(sources, device=None, host_loader=None):
     """Device-side ``pil_loader`` over a list of paths / file contents: decoded uint8 H x W x 3 tensors on the device, in input order.
-    Baseline JPEG files go through ``decode_many`` (one call for all of them).  A file the device decoder does not take (PNG,
-    progressive JPEG, ...) raises the ValueError of ``parse`` -- unless the caller passes ``host_loader``, a callable
+    Baseline and progressive JPEG files go through ``decode_many`` (one call per kind).  A file the decoder does not take (PNG,
+    arithmetic-coded or CMYK JPEG, ...) raises the ValueError of ``parse`` -- unless the caller passes ``host_loader``, a callable
     ``bytes -> H x W x 3 uint8 array`` (the reference's own ``pil_loader`` is the natural one); its result is uploaded as is.
     Nothing in this module decodes on the host by itself."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -265,6 +265,9 @@ typedef struct gdt_jpeg_info {
     unsigned short quant[4][64];               /* natural (row-major) order */
     unsigned char huff_bits[4][17];            /* tables 0-1: DC 0 / 1, 2-3: AC 0 / 1; bits[l] = number of codes of length l */
     unsigned char huff_vals[4][256];
+    int progressive;                           /* 1: SOF2 (progressive DCT, Huffman): scan_offset = the first SOS marker; decoded through
+                                                  gdt_jpeg_progressive_coefficients + gdt_jpeg_decode_coef_u8_batch (below) */
+    int comp_id[3];                            /* progressive files: the frame's component identifiers (their scans name components by id) */
 } gdt_jpeg_info;
 int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info);
 int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off);
@@ -282,6 +285,20 @@ typedef struct gdt_jpeg_item {
 } gdt_jpeg_item;
 int gdt_jpeg_decode_workspace_bytes(const gdt_jpeg_item* items, int n, size_t* bytes);
 int gdt_jpeg_decode_u8_batch(const gdt_jpeg_item* items, int n, int mode, void* workspace, size_t workspace_bytes, void* stream);
+/* Progressive files (SOF2: spectral selection + successive approximation, Huffman-coded; what pil_loader opens just as well,
+ * datahelpers.py:39-47).  Their scans refine the SAME coefficients several times over, so the entropy decoding is a sequential pass per
+ * scan: gdt_jpeg_progressive_coefficients (host, pure C; ITU T.81 Annex G) walks every scan of one file and writes the quantised
+ * coefficients, DC prediction resolved, in the block order of the device pipeline (MCU by MCU, luma blocks first), 64 natural-order
+ * int16 per block: info->mcus_x * mcus_y * blocks_per_mcu blocks.  gdt_jpeg_progressive_coefficients_batch: the same for a list on a few
+ * host threads, file i at coef + coef_off[i] elements.  gdt_jpeg_decode_coef_u8_batch (device): dequantisation + inverse DCT, upsampling,
+ * colour conversion of n images whose coefficients lie at coef_dev + coef_off[i] (one device buffer): the back half of
+ * gdt_jpeg_decode_u8_batch, same arithmetic, same [height][width][3] uint8 output.  Baseline files may be decoded this way too. */
+int gdt_jpeg_progressive_coefficients(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, short* coef);
+int gdt_jpeg_progressive_coefficients_batch(const unsigned char* const* files, const size_t* nbytes, const gdt_jpeg_info* infos, int n, short* coef,
+                                            const size_t* coef_off, int* status, int threads);
+int gdt_jpeg_decode_coef_workspace_bytes(const gdt_jpeg_info* infos, int n, size_t* bytes);
+int gdt_jpeg_decode_coef_u8_batch(const gdt_jpeg_info* infos, const short* coef_dev, const size_t* coef_off, unsigned char* const* dst_hwc, int n,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Learned whitening ("next" row of SURVEY.md section 8f, rank 4): the {m, P} that gdt_whiten applies

@@ -1,4 +1,4 @@
-"""Golden vectors for the device JPEG decoder: small baseline files written by Pillow and what the reference's loader makes of them,
+"""Golden vectors for the device JPEG decoder: small baseline and progressive files written by Pillow and what the reference's loader makes of them,
 ``np.asarray(Image.open(f).convert('RGB'))`` (pil_loader, mdir/external/cirtorch/datasets/datahelpers.py:39-47).  The decoder the
 reference calls IS Pillow (libjpeg-turbo), so these vectors are outputs of the reference's own code path; the tests check the device
 decoder against them and, where Pillow is installed, that Pillow still reproduces them (i.e. that the fixture pins the library build).
@@ -39,6 +39,11 @@ CASES = [  # name, (w, h), gray, save options
     ("c444_q100", (24, 24), False, dict(quality=100, subsampling=0)),
     ("c420_restart_rows", (70, 50), False, dict(quality=85, subsampling=2, restart_marker_rows=1)),
     ("c444_restart_blocks", (40, 40), False, dict(quality=85, subsampling=0, restart_marker_blocks=3)),
+    # progressive (SOF2): spectral selection + successive approximation, libjpeg's default scan script
+    ("p420_q85", (64, 48), False, dict(quality=85, subsampling=2, progressive=True)),
+    ("p444_q60_odd", (37, 29), False, dict(quality=60, subsampling=0, progressive=True, optimize=True)),
+    ("pgray_q75", (40, 29), True, dict(quality=75, progressive=True)),
+    ("p422_restart", (51, 30), False, dict(quality=80, subsampling=1, progressive=True, restart_marker_blocks=2)),
 ]
 
 

@@ -27,6 +27,8 @@ def _picture(w, h, seed, gray=False):
 
 
 def _encode(img, **kw):
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 22)      # (Pillow's progressive / optimising encoder needs the whole file in one buffer)
     buf = io.BytesIO()
     img.save(buf, "JPEG", **kw)
     return buf.getvalue()
@@ -101,25 +103,49 @@ def test_batch_of_mixed_files_equals_one_by_one():
 
 
 def test_unsupported_files_raise_and_host_loader_is_explicit():
-    progressive = _encode(_picture(64, 64, 1), quality=80, progressive=True)
     cmyk = _encode(_picture(32, 32, 2).convert("CMYK"), quality=80)
     png = io.BytesIO()
     _picture(20, 20, 3).save(png, "PNG")
-    for blob, word in ((progressive, "progressive"), (cmyk, "three-component"), (png.getvalue(), "SOI")):
+    for blob, word in ((cmyk, "three-component"), (png.getvalue(), "SOI")):
         with pytest.raises(ValueError, match=word):
             jpeg.parse(blob)
     good = _encode(_picture(48, 40, 4), quality=90)
     with pytest.raises(ValueError):
-        jpeg.load_many([good, progressive], "cuda:0")
+        jpeg.load_many([good, cmyk], "cuda:0")
     calls = []
 
     def loader(data):
         calls.append(len(data))
         return _reference(data)
 
-    out = jpeg.load_many([good, progressive], "cuda:0", host_loader=loader)
-    assert calls == [len(progressive)]
-    assert np.array_equal(out[0].cpu().numpy(), _reference(good)) and np.array_equal(out[1].cpu().numpy(), _reference(progressive))
+    out = jpeg.load_many([good, cmyk], "cuda:0", host_loader=loader)
+    assert calls == [len(cmyk)]
+    assert np.array_equal(out[0].cpu().numpy(), _reference(good)) and np.array_equal(out[1].cpu().numpy(), _reference(cmyk))
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2], ids=["444", "422", "420"])
+def test_progressive_files_match_pillow(subsampling):
+    """SOF2 files (spectral selection + successive approximation: what Pillow writes with progressive=True, libjpeg's default scan script of
+    10 scans for colour) -- coefficients by the library's host decoder, everything behind it on the device: byte-exact with pil_loader"""
+    blobs = [_encode(_picture(w, h, 70 + k), quality=q, subsampling=subsampling, progressive=True, optimize=(k % 2 == 0))
+             for k, ((w, h), q) in enumerate(zip(SIZES, [90, 75, 50, 95, 85, 30, 60, 100, 80, 92]))]
+    for b in blobs:
+        assert jpeg.parse(b).info.progressive == 1
+    _check(blobs)
+
+
+def test_progressive_grayscale_restarts_and_mixed_lists():
+    gray = [_encode(_picture(w, h, 90 + k, gray=True), quality=q, progressive=True) for k, ((w, h), q) in enumerate(zip(SIZES[2:8], [95, 20, 70, 85, 50, 99]))]
+    _check(gray)
+    # restart intervals inside progressive scans (end-of-band runs and DC predictions restart with them)
+    rst = [_encode(_picture(96, 80, 120 + k), quality=85, subsampling=s, progressive=True, restart_marker_blocks=b) for k, (s, b) in enumerate([(0, 3), (2, 2), (1, 5)])]
+    _check(rst)
+    # one list of baseline and progressive files: one library call per kind, results in input order
+    mixed = [_encode(_picture(64, 48, 130), quality=80), rst[0], _encode(_picture(31, 45, 131), quality=90, progressive=True),
+             _encode(_picture(80, 64, 132, gray=True), quality=70), gray[1]]
+    _check(mixed)
+    with pytest.raises(ValueError, match="truncated"):
+        jpeg.decode_many([rst[1][: 2 * len(rst[1]) // 3]], "cuda:0")
 
 
 def test_files_to_network_input_matches_the_pillow_pipeline():

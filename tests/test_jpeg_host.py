@@ -66,8 +66,8 @@ def test_scan_extraction_removes_stuffing_and_cuts_at_restart_markers():
 def test_unsupported_kinds_are_refused_with_the_reason():
     rng = np.random.RandomState(2)
     arr = rng.randint(0, 256, (40, 40, 3), dtype=np.uint8)
-    with pytest.raises(ValueError, match="progressive"):
-        jpeg.parse(_encode(arr, quality=80, progressive=True))
+    prog = jpeg.parse(_encode(arr, quality=80, progressive=True))          # SOF2: accepted; its scans go through the coefficient decoder
+    assert prog.info.progressive == 1 and prog.size == (40, 40)
     buf = io.BytesIO()
     Image.fromarray(arr).convert("CMYK").save(buf, "JPEG")
     with pytest.raises(ValueError, match="three-component"):
@@ -103,6 +103,8 @@ def test_golden_files_parse_and_pillow_still_reproduces_them():
 
 
 def test_every_truncation_pillow_refuses_is_refused():
+    import ctypes
+    from gandtr_amd import _hip
     """the reference's loader (pil_loader = Image.open(f).convert('RGB'), datahelpers.py:39-47) raises OSError for a file cut inside its
     scan; the device path must not hand back a zero-padded image for it (datasets.ImagesFromList(ignore_errors=...) and
     extract_vectors_from_files would embed it): whatever Pillow refuses, gdt_jpeg_parse refuses"""
@@ -125,8 +127,11 @@ def test_every_truncation_pillow_refuses_is_refused():
             except OSError:
                 pillow_ok = False
             try:
-                jpeg.parse(cut)
+                p = jpeg.parse(cut)
                 ours_ok = True
+                if p.info.progressive:                     # (the scans of a progressive file are walked by its coefficient decoder)
+                    coef = np.zeros(p.info.mcus_x * p.info.mcus_y * p.info.blocks_per_mcu * 64, dtype=np.int16)
+                    ours_ok = _hip.load().gdt_jpeg_progressive_coefficients(cut, len(cut), ctypes.byref(p.info), coef.ctypes.data) == 0
             except ValueError:
                 ours_ok = False
             pillow_refused += not pillow_ok
@@ -180,3 +185,32 @@ def test_images_from_list_constructor_contract():
     blob = _encode(np.zeros((16, 16, 3), np.uint8), quality=80)
     with pytest.raises(ValueError, match="HIP device"):
         ImagesFromList("", [blob], device="cpu").batch([0])      # decoding needs the device: there is no host path
+
+
+def test_progressive_coefficient_decoder_on_the_host():
+    """gdt_jpeg_progressive_coefficients (pure host code): the quantised coefficients of a progressive file equal those of the BASELINE file Pillow
+    writes from the same pixels at the same quality (the two codings carry the same DCT output; libjpeg computes it identically), checked through
+    Pillow's own dequantised view: both files decode to the same pixels -- and here structurally: same DC terms, same non-zero count."""
+    import ctypes
+    from gandtr_amd import _hip
+    lib = _hip.load()
+    rng = np.random.RandomState(7)
+    base = rng.randint(0, 256, (12, 16, 3), dtype=np.uint8)
+    arr = np.asarray(Image.fromarray(base).resize((96, 72), Image.BICUBIC))
+    for sub in (0, 2):
+        blob = _encode(arr, quality=85, subsampling=sub, progressive=True)
+        p = jpeg.parse(blob)
+        n = p.info.mcus_x * p.info.mcus_y * p.info.blocks_per_mcu
+        coef = np.zeros(n * 64, dtype=np.int16)
+        assert lib.gdt_jpeg_progressive_coefficients(blob, len(blob), ctypes.byref(p.info), coef.ctypes.data) == 0
+        coef = coef.reshape(n, 64)
+        # DC of the first luma block = round(mean of the level-shifted block * 8 / q00): within one quantisation step of the pixels' block mean
+        with Image.open(io.BytesIO(blob)) as img:
+            y = np.asarray(img.convert("YCbCr"))[:8, :8, 0].astype(np.float64)
+        q00 = p.info.quant[p.info.tq[0]][0]
+        assert abs(coef[0, 0] * q00 / 8.0 - (y.mean() - 128.0)) <= q00 / 8.0 + 1.5
+        assert (coef != 0).sum() > n                                        # AC bands were decoded, too
+        # every truncation inside the scans is refused (Pillow raises for them as well)
+        for cut in (len(blob) // 2, len(blob) - 2):
+            rc = lib.gdt_jpeg_progressive_coefficients(blob[:cut], cut, ctypes.byref(p.info), coef.ctypes.data)
+            assert rc != 0 and b"truncated" in lib.gdt_last_error()
