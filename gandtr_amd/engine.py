@@ -35,7 +35,7 @@ def _ptr(a):
 
 
 class HipNet:
-    """One layer graph living on one GPU.  Not re-entrant (same rule as the C handle)."""
+    """One layer graph living on one GPU.  Host calls are serialised per handle (one thread at a time; see forward_many for what may overlap on the device)."""
 
     PRECISIONS = {"f16": 0, "f16x3": 1, "f16c": 2, "f16ch": 3}       # include/gandtr_hip.h, gdt_net_set_precision
 
@@ -230,7 +230,13 @@ class HipNet:
         """Several independent forwards -- ``inputs`` = [(x, scale or None), ...], e.g. the levels of the multi-scale pyramid
         (CirMultiscaleAggregation, wrapper.py:225-263) -- issued on one side stream each, every one with its own scratch buffer, and joined
         on the caller's stream.  A level at batch 8 leaves most of the chip idle (layer3 of ResNet-101 at scale 1/2: 32 patch tiles for
-        256 CUs); the levels' kernels fill each other's gaps.  Results are those of ``forward`` called level by level."""
+        256 CUs); the levels' kernels fill each other's gaps.  Results are those of ``forward`` called level by level.
+
+        Invariant this relies on (and the C handle states, include/gandtr_hip.h): the HOST calls on one ``gdt_net`` are serialised -- each
+        ``gdt_net_forward`` plans its geometry into the handle and enqueues its launches before it returns -- and every byte of per-forward
+        DEVICE state lives in the caller's workspace, so several forwards of one handle may be in flight on different streams as long as each
+        has its own workspace and they are issued from one host thread at a time.  The side workspaces are kept between calls up to
+        ``side_workspace_cap`` bytes in total (default 8 GiB); beyond it they are released when the call returns."""
         if not self._finalized:
             raise RuntimeError("HipNet.forward_many before finalize()")
         if len(inputs) == 1 or getattr(self, "_profiling", False) or os.environ.get("GANDTR_HIP_CONCURRENT_LEVELS", "1") == "0":
@@ -266,6 +272,12 @@ class HipNet:
                 cur.wait_stream(pools["streams"][k])
                 for o in results[k]:
                     o.record_stream(cur)
+            held = sum(w.numel() for w in pools["ws"] if w is not None)
+            if held > getattr(self, "side_workspace_cap", 8 << 30):
+                for k, w in enumerate(pools["ws"]):
+                    if w is not None:
+                        w.record_stream(cur)
+                        pools["ws"][k] = None
         return results
 
     def _capture(self, x, key, need, shapes):

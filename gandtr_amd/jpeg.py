@@ -74,15 +74,27 @@ def parse_many(blobs):
     return out
 
 
-_stage = None
+import threading
+
+_stages = {}                    # (thread id, device index) -> [pinned buffer, event recorded behind its last upload]
+_stages_lock = threading.Lock()
 
 
-def _staging(nbytes):
-    """pinned upload buffer, grown geometrically and kept (allocating pinned memory costs more than decoding a small file)"""
-    global _stage
-    if _stage is None or _stage.numel() < nbytes:
-        _stage = torch.empty(max(nbytes, 1 << 20) * 3 // 2, dtype=torch.uint8).pin_memory()
-    return _stage[:nbytes]
+def _staging(nbytes, device):
+    """Pinned upload buffer of THIS thread for ``device``, grown geometrically and kept (allocating pinned memory costs more than decoding a
+    small file).  Before it is rewritten the event recorded behind the previous upload from it is awaited -- whichever stream that upload
+    ran on -- so a caller on another stream, device or thread can never overwrite bytes that are still in flight."""
+    key = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    with _stages_lock:
+        entry = _stages.get(key)
+        if entry is None or entry[0].numel() < nbytes:
+            if entry is not None and entry[1] is not None:
+                entry[1].synchronize()
+            entry = [torch.empty(max(nbytes, 1 << 20) * 3 // 2, dtype=torch.uint8).pin_memory(), None]
+            _stages[key] = entry
+    if entry[1] is not None:
+        entry[1].synchronize()
+    return entry[0][:nbytes], entry
 
 
 def _decode_progressive(parsed, device):
@@ -154,8 +166,7 @@ def decode_many(blobs, device=None, sequential=False):
         total += (int(p.info.scan_capacity) + 15) // 16 * 16
         seg_index.append(nseg)
         nseg += p.info.nsegments + 1
-    torch.cuda.current_stream(device).synchronize()      # (an upload from the staging buffer may still be in flight)
-    stage = _staging(total)
+    stage, stage_entry = _staging(total, device)
     seg_all = (ctypes.c_uint * nseg)()
     infos = (_hip.JpegInfo * n)(*[p.info for p in parsed])
     files, keep = _ptr_array([p.data for p in parsed])
@@ -164,6 +175,8 @@ def decode_many(blobs, device=None, sequential=False):
     seg_base = ctypes.addressof(seg_all)
     with torch.cuda.device(device):
         scans = stage.to(device, non_blocking=True)
+        stage_entry[1] = torch.cuda.Event()
+        stage_entry[1].record(torch.cuda.current_stream())
         out_offs, out_total = [], 0
         for p in parsed:
             out_offs.append(out_total)

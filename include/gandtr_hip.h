@@ -11,7 +11,7 @@
  *   - every function returns 0 (GDT_OK) or a positive status; gdt_last_error() returns the thread-local message.
  *     The Python binding re-raises GDT_ERR_INVALID as ValueError / AssertionError like the reference's own checks
  *     (SURVEY.md section 8b "Error conventions").
- *   - a gdt_net is bound to the device that was current at gdt_net_finalize() and is not re-entrant.
+ *   - a gdt_net is bound to the device that was current at gdt_net_finalize(); host calls on one handle must be serialised (see gdt_net_forward).
  *   - ownership: the caller (PyTorch) owns all input / output / workspace buffers; a net owns its packed weights.
  *   - external images are fp32 NCHW (the reference's layout); internal activations are fp16 NHWC.
  */
@@ -119,6 +119,9 @@ int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes);
 
 /* Run the graph.  x: device fp32 [n][c][h][w].  If (rh, rw) != (h, w) the input is bilinearly resized with torch's
  * scale_factor semantics, rscale = (float)(1.0 / scale_factor).  outputs[i] is the device buffer of external slot i. */
+/* Threading: host calls on one handle must be serialised (each call plans its geometry into the handle before it enqueues its launches); all
+ * per-forward DEVICE state lives in the caller's workspace, so forwards of one handle may overlap on the device when each is given its own
+ * workspace and stream (HipNet.forward_many does that for the levels of the multi-scale pyramid). */
 int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
                     void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream);
 

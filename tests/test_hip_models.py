@@ -296,3 +296,26 @@ def test_pyramid_levels_issued_concurrently_equal_level_by_level(cuda_device):
         for g, w in zip(got, want):
             assert torch.equal(g[net.out_slot], w)
         assert torch.equal(net.forward(x)[net.out_slot], want[0])
+
+
+def test_forward_many_equals_level_by_level_forward(cuda_device):
+    """HipNet.forward_many (the pyramid levels of one handle in flight on side streams, own workspaces) == forward called level by level, bit for
+    bit, for mixed geometries: a level that runs the direct stem (no resize, fp32 image straight into the first conv) and resized levels
+    (input pack + general stem).  Also after the side workspaces were released by the cap."""
+    from gandtr_amd import engine
+    sd = synth.resnet101_state(0)
+    net = engine.build_embedder(sd, cuda_device)
+    x = synth.synth_input(77, (2, 3, 320, 256)).to(cuda_device)
+    x2 = synth.synth_input(78, (3, 3, 192, 224)).to(cuda_device)
+    levels = [(x, None), (x, 2 ** -0.5), (x, 0.5), (x2, None), (x2, 2 ** 0.5)]
+    want = [[o.clone() for o in net.forward(xx, scale=s)] for xx, s in levels]
+    got = net.forward_many(levels)
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert len(w) == len(g) and all(torch.equal(a, b) for a, b in zip(w, g))
+    net.side_workspace_cap = 0                                            # release the per-level workspaces after every call
+    got2 = net.forward_many(levels)
+    torch.cuda.synchronize()
+    assert all(w is None for w in net._side["ws"])
+    for w, g in zip(want, got2):
+        assert all(torch.equal(a, b) for a, b in zip(w, g))
