@@ -101,14 +101,28 @@ def gem_resnet101_hedngan(pretrained=True, device=None):
 
 
 def cyclegan(pretrained=True, device=None):
-    """ResNet CycleGAN day->night generator (InstanceNorm)."""
+    """ResNet CycleGAN day->night generator (InstanceNorm).
+
+    Precision on a HIP device (the reference computes in fp32; ``device='cpu'`` runs the stock torch modules): the default conv arithmetic is
+    "f16c" -- fp32 activations, fp16 MFMA product + block-scaled correction product -- which holds north_star's gate of 1e-3 of the PRE-TANH
+    range at every tap (measured 4.4-4.9e-4).  The image error is that relative error times max|pre-tanh|: the absolute image gate
+    max|d| <= 1e-3 holds up to max|pre-tanh| ~ 2 in "f16c", up to ~ 3 in "f16ch" (head compensated too, -5 % images/s), and "f16x3" is exact to
+    3e-6 at 0.38 x the speed; "f16" (single pass, 2.5e-3) is outside the tolerance.  Select with ``net.model.hip_precision = "f16ch"`` or the
+    environment variable GANDTR_HIP_PRECISION=f16|f16c|f16ch|f16x3."""
     if pretrained:
         return _create(GENERATOR_SCENARIO, {"path": BASE_URL + "cyclegan_generator_X.pth"}, pretrained, device)
     return _create(GENERATOR_SCENARIO, {}, pretrained, device)
 
 
 def hedngan(pretrained=True, device=None):
-    """ResNet HED-N-GAN day->night generator (BatchNorm, kaiming init when not pretrained)."""
+    """ResNet HED-N-GAN day->night generator (BatchNorm, kaiming init when not pretrained).
+
+    Precision on a HIP device (the reference computes in fp32; ``device='cpu'`` runs the stock torch modules): the default conv arithmetic is
+    "f16c" -- fp32 activations, fp16 MFMA product + block-scaled correction product -- which holds north_star's gate of 1e-3 of the PRE-TANH
+    range at every tap (measured 4.4-4.9e-4).  The image error is that relative error times max|pre-tanh|: the absolute image gate
+    max|d| <= 1e-3 holds up to max|pre-tanh| ~ 2 in "f16c", up to ~ 3 in "f16ch" (head compensated too, -5 % images/s), and "f16x3" is exact to
+    3e-6 at 0.38 x the speed; "f16" (single pass, 2.5e-3) is outside the tolerance.  Select with ``net.model.hip_precision = "f16ch"`` or the
+    environment variable GANDTR_HIP_PRECISION=f16|f16c|f16ch|f16x3."""
     if pretrained:
         return _create(GENERATOR_SCENARIO, {"path": BASE_URL + "hedngan_generator_X.pth"}, pretrained, device)
     return _create(GENERATOR_SCENARIO, {"model.norm_layer": "batch", "initialize.weights": "kaiming_p2p"}, pretrained, device)

@@ -387,3 +387,22 @@ def test_restricted_checkpoint_loader_names_the_offending_type(tmp_path):
     assert load_restricted(good)["model_state"]["w"].sum() == 2
     with pytest.raises(RuntimeError, match="add_safe_globals"):
         load_restricted(bad)
+
+
+def test_precision_contract_and_env_knob(monkeypatch):
+    """The precision contract of the HIP path is visible at the boundary (README first screen, hub/model.py docstrings): generators
+    default to "f16c" (north_star's 1e-3 of the pre-tanh range), embedders and HED to "f16"; GANDTR_HIP_PRECISION overrides the family default on a
+    hub object, a per-module ``hip_precision`` overrides both."""
+    monkeypatch.delenv("GANDTR_HIP_PRECISION", raising=False)
+    gen = hubconf.cyclegan(pretrained=False, device="cpu")
+    emb = hubconf.gem_vgg16_cyclegan(pretrained=False, device="cpu")
+    assert gen.model._hip_precision() == "f16c" and emb.model._hip_precision() == "f16"
+    monkeypatch.setenv("GANDTR_HIP_PRECISION", "f16x3")
+    assert gen.model._hip_precision() == "f16x3" and emb.model._hip_precision() == "f16x3"
+    gen.model.hip_precision = "f16ch"
+    assert gen.model._hip_precision() == "f16ch"
+    monkeypatch.delenv("GANDTR_HIP_PRECISION")
+    assert gen.model._hip_precision() == "f16ch" and emb.model._hip_precision() == "f16"
+    import gandtr_amd.hub.model as hub_model
+    for fn in (hub_model.cyclegan, hub_model.hedngan):
+        assert "f16c" in fn.__doc__ and "1e-3" in fn.__doc__ and "f16x3" in fn.__doc__
