@@ -384,10 +384,17 @@ def main():
             print("mfma-only measurement failed: %r" % (exc,), file=sys.stderr)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
-    roof = conv_roofline(gen, xg, traffic_key="r03_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    roof = conv_roofline(gen, xg, traffic_key="r04_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
     if roof is not None:
         # the kernel issues 1.5 MFMA-slots per algorithmic fp16 one (1 fp16 + 1/2 block-scaled): its matrix pipe work is 1.5 x `achieved`
         roof["mfma_work_factor"] = 1.5
+        # what this precision mode can reach at all: the datasheet peak over its 1.5 MFMA slots per algorithmic one (at 2.4 GHz, which the chip does not
+        # hold under matrix load), and what the bare instruction mix sustains against the power governor on these boxes (operands in registers,
+        # profiles/experiments/mfma_shape_probe.hip -> profiles/r04_mfma_shape_probe.log: 32 x 32 shapes 1045, 16 x 16 shapes 1194 TFLOP/s)
+        roof["mode_ceiling"] = round(PEAK_F16_TFLOPS / 1.5, 1)
+        roof["frac_of_mode_ceiling"] = round(roof["achieved"] / (PEAK_F16_TFLOPS / 1.5), 4)
+        roof["mode_sustained_mfma_only"] = {"32x32x16+32x32x64": 1045.0, "16x16x32+16x16x128": 1194.0, "unit": "TFLOP/s algorithmic",
+                                            "source": "profiles/r04_mfma_shape_probe.log"}
     if roof is not None and mfma_only:
         roof["mfma_only_sustained"] = mfma_only
         roof["frac_of_mfma_only"] = round(roof["achieved"] / mfma_only, 4)

@@ -10,16 +10,31 @@
 // = 1.5x the fp16 work at the fp4/fp6 MFMA rate (measured 1.43x, profiles/experiments/mx_probe.hip) instead of 3x.  Measured
 // against the fp32 oracle: <= 4e-4 at every tap of the full-size generator (single-pass fp16: 2.5e-3; f16x3: 3e-6).
 //
-// Structure = conv3x3_halo_rb.hip (persistent workgroups, 16x16 output patch x 256 output channels, 8 waves of 128 x 64,
-// LDS-resident halo, weights streamed L2 -> registers in fragment order, swapped MFMA operands D[cout][pixel]).  Differences:
-//   * the halo is read as fp32 (32 bytes per 8-channel piece), normalised / ReLU'd / residual-added in fp32 (the producer's
-//     InstanceNorm folded in, MODE bits as in the fp16 kernel), then split: fp16 hi plane (128-byte rows, same swizzle) and an
-//     fp4 plane (64-byte rows: [lo 0-31][hi 0-31][lo 32-63][hi 32-63], v_cvt_scalef32_pk_fp4_*), both written to LDS;
-//   * per tap step: 32 fp16 MFMAs + 16 MX MFMAs per wave; MX weight fragments (24 bytes per lane: lanes 0-31 w_hi, lanes 32-63 w_lo
-//     of the same 32 k-values, e2m3, block scale byte per lane) stream from L2 like the fp16 ones;
-//   * epilogue straight from the accumulators: a lane holds 4 consecutive output channels of one pixel = one 16-byte fp32
-//     store (no LDS transpose, so the two halo stages may use 126 KB of LDS); InstanceNorm statistics by a halving butterfly
-//     over the 32 pixel lanes (31 shuffles per column block), fixed order => deterministic.
+// Structure (the shipped forms; conv3x3_halo_c16.hip is the same layer on the 16 x 16 MFMA shapes and takes the 256-column resblock convs of whole
+// 16 x 16 patches since round 4 -- this file keeps the 128-column form for few patches, ragged image sizes, and the shift forms):
+//   * persistent workgroups walking an XCD-chunked tile list; a tile = a 16 x 16 output patch x 256 (or 128) output channels; swapped MFMA
+//     operands, D[cout][pixel] = W . A^T;
+//   * FOUR waves, one per SIMD, 512 registers each (256 accumulator AGPRs + 256 VGPRs), laid out 1 x 4 in the 3x3 and stride-2 forms: every wave
+//     owns all 256 pixels x 64 output channels, so a weight fragment feeds 8 MFMAs (half the L1 weight bytes per MFMA of a 2 x 2 layout, twice its LDS
+//     fragment bytes); the transposed form and the 128-column tiles keep 2 x 2 waves (its phase-per-block map needs four blocks per wave); an
+//     experimental 1 x 8 layout -- two waves per SIMD at 256 registers, each 256 pixels x 32 channels -- exists behind GDT_C_WAVES=8 (same cycles,
+//     lower clock: off);
+//   * the halo (18 x 18 per 64-channel chunk; 17 x 17 in the shift forms) is read as fp32 through registers, branch-free, one loader round in flight per
+//     thread, normalised / ReLU'd / residual-added in fp32 (the producer's InstanceNorm folded in: MODE bits 1 norm, 2 + residual, 4 + write-back of
+//     the transformed tensor), then split by v_cvt_pk_f16_f32 / v_fma_mix_f32 / v_cvt_scalef32_pk_fp4_*: fp16 hi plane (128-byte rows, XOR swizzle) and
+//     an fp4 plane (64-byte rows: [lo 0-31][hi 0-31][lo 32-63][hi 32-63], own swizzle), two stages in LDS, one barrier per chunk;
+//   * weights stream L2 -> registers in MFMA fragment order: fp16 fragments in a ring of 3-4 substep slices, MX fragments (a lane's 32 e2m3 values = 16 + 8
+//     bytes + an E8M0 scale dword, three contiguous arrays) loaded INTO the MFMA's 6-register operand tuple; scalar-base addressing;
+//   * per k-substep (16 k-values): 16 fp16 MFMAs per wave, every second substep 16 MX MFMAs on the 32 k-values just done; MFMAs row-outer, the
+//     activation fragment re-loaded in place; sched_group_barrier lays the substep out as MFMA, one LDS read, <= 4 VALU, a memory operation per two MFMAs;
+//   * epilogue, wave-private and software-pipelined: every 32 x 32 accumulator block goes through a 4 KB XOR-swizzled patch of the wave's own (two
+//     patches: block n + 1 is written while block n's four row reads are in flight) and leaves as whole 128-byte lines; interior tiles run a
+//     branch-free body (running per-lane store offset, ReLU as a max with 0 / -inf, the epilogue residual of the BatchNorm generator fetched one
+//     block ahead); InstanceNorm statistics: ONE 256-row record per wave (the second 128-row record of the slab layout is written as zeros), the
+//     8 pixel lanes merged by a DPP rotate + a swizzle + one permute per value, fixed order => deterministic;
+//   * FORM 1 (transposed): a wave's four 32-column blocks are the four sub-pixel phases of 32 output channels, so the 7 zero (shift, phase) blocks of 16
+//     are skipped at compile time; FORM 2 (stride 2): the loader reads the virtual space-to-depth view of its input, 9 of the 16 (shift, parity) blocks
+//     are non-zero (skipped per chunk: compile-time masks in the 128-column form, run-time in the 256-column one).
 #include <cstdio>
 #include <cstdlib>
 

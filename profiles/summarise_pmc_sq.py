@@ -27,7 +27,7 @@ def short(name):
 
 
 def main():
-    root, out_path, filters = sys.argv[1], sys.argv[2], sys.argv[3:] or ["conv3x3_halo_c_kernel"]
+    root, out_path, filters = sys.argv[1], sys.argv[2], sys.argv[3:] or ["conv3x3_halo_c"]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         with open(path) as f:
