@@ -310,7 +310,9 @@ def main():
         r, ms = rate(lambda: ingest.ingest(photo, 1024, mean, std), 1, steps=200, warmup=10)
         r2, _ = rate(lambda: ingest.ingest(photo, 1024, mean, std, clahe_clip=1.0), 1, steps=200, warmup=10)
         out["next_ingest_1200x1600_to_1024"] = {"images_per_s": r, "us": round(1e6 / r, 1), "with_clahe_images_per_s": r2,
-                                                "with_clahe_us": round(1e6 / r2, 1)}
+                                                "with_clahe_us": round(1e6 / r2, 1),
+                                                "note": "wall time per Python call of ingest.ingest, calls back to back: host-bound (wrapper + output allocation + "
+                                                        "launches); the two resampling kernels themselves take 16.9 + 7.6 us (profiles/r01_ingest_1200x1600_kernel_stats.csv)"}
         rng = np.random.default_rng(1)                      # a list of 64 photos of mixed sizes through the batched entry point (one call)
         mixed = [torch.from_numpy(rng.integers(0, 256, (int(h), int(w), 3)).astype(np.uint8)).to(dev)
                  for h, w in zip(rng.integers(700, 1500, 64), rng.integers(900, 2000, 64))]

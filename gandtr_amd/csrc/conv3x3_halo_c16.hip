@@ -48,7 +48,7 @@
 #define GDT_C16_BQ_SETS 1       // register sets of the MX weights: 2 = the set of tap t + 1 is fetched during tap t (measured: no faster -- the weight stream is
 #endif                          // throughput-, not latency-bound -- and 28 registers that the second halo round in flight needs more)
 #ifndef GDT_C16_ABL
-#define GDT_C16_ABL 0           // timing-only ablations: 1 no halo staging   2 no MX MFMAs / loads   4 no fp16 weight re-loads   8 no fp4 fragment re-loads   16 no MX weight re-loads
+#define GDT_C16_ABL 0           // timing-only ablations: 1 no halo staging   2 no MX MFMAs / loads   4 no fp16 weight re-loads   8 no fp4 fragment re-loads   16 no MX weight re-loads   64 MX weights fetched into an unused set   128 every weight fetch from one hot 7 KB window   256 no output stores
 #endif
 
 namespace {
