@@ -148,6 +148,8 @@ def kernel_name(variant):
         return "conv1x1_rb_kernel"
     if variant >= 940000:
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
+    if variant >= 939000:
+        return "conv3x3_expand_rb_kernel<%d>" % ((variant - 939000) * 8)   # Bottleneck 3x3 + expand 1x1 + residual in one launch
     if variant >= 935000:                                   # (+1: the projection-shortcut form)
         return "conv_bneck_kernel<%d>%s" % ((variant - 935000) & ~1, "[projection]" if (variant & 1) else "")
     if variant >= 930000:

@@ -480,6 +480,8 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     static const int persist = [] { const char* e = getenv("GDT_RB_PERSIST"); return e ? atoi(e) : 1; }();
     int grid = (vblocks < cus || !persist) ? vblocks : cus * (persist > 1 ? persist : 1) / (persist > 1 ? 2 : 1);
+    static const int cu_limit = [] { const char* e = getenv("GDT_CU_LIMIT"); return e ? atoi(e) : 0; }();      // dev: persistent grid on part of the chip (concurrent-stream experiments)
+    if (cu_limit > 0 && grid > cu_limit) grid = cu_limit;
     if (SINGLE) grid = vblocks < 2 * cus ? vblocks : 2 * cus;
     hipLaunchKernelGGL((conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT, SINGLE>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, d, vblocks);
     GDT_CHECK_HIP(hipGetLastError());

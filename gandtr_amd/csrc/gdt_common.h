@@ -93,6 +93,10 @@ struct ConvLaunch {
     // the same tile -- out = W . in + W2 . in2 with the weights packed as ONE [CoutPad][Cin + in2_cin] matrix (Kpad = Cin + in2_cin): the projection
     // shortcut of a ResNet Bottleneck folded into its expand conv
     const f16* in2; int in2_cin, in2_h, in2_w, in2_stride;
+    // conv3x3_expand_rb.hip: the Bottleneck's expand conv run on the 3x3's tile while it is in LDS -- out = ReLU(res + x_w . ReLU(conv3x3 + bias) + x_bias);
+    // x_w_frag in the fragment order of w_frag with K = Cout of the 3x3; x_bias: the expand's bias as one weight fragment per 32 channels (lane (c, 0) =
+    // { fp16(b), fp16(b - fp16(b)), 0 .. }: it is added by an MFMA against a { 1, 1, 0 .. } pixel operand); `out`, `res` have x_cout channels
+    const f16* x_w_frag; const f16* x_bias; int x_cout;
 };
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>
@@ -116,6 +120,8 @@ bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d);    // conv_igemm.hip: fu
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip (weights streamed into registers)
+bool gdt_conv3x3_expand_eligible(const ConvLaunch& d);     // conv3x3_expand_rb.hip (3x3 + expand 1x1 + residual of a Bottleneck, variant 939000 + x_cout / 8)
+int gdt_launch_conv3x3_expand(const ConvLaunch& d, hipStream_t stream);
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_pool2_eligible(const ConvLaunch& d);         // conv_igemm.hip: can this launch (pool2 = 0) take a fused 2x2 max pool?
 bool gdt_conv_halo_ct_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip, transposed form (variant 960256)

@@ -47,6 +47,7 @@ struct Op {
     int cin_pad = 0, cout_pad = 0;
     std::vector<PackedPhase> phases;
     size_t bias_off = 0; bool has_bias = false;
+    size_t bias_frag_off = 0; bool has_bias_frag = false;    // 1x1 convs from 256 channels: the bias as an MFMA weight fragment (conv3x3_expand_rb.hip)
     // input
     int in_c = 0; int perm[8]; float scale[8], shift[8];
     // inorm
@@ -161,6 +162,7 @@ struct Step {
     bool bneck;      // CONV: first conv of a Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2 (identity shortcut) ...
     int bneck_ds;    // ... or {reduce, 1x1 projection shortcut} in either order at i, i + 1 (bneck_a / bneck_ds), i + 2 (3x3), i + 3 (expand + shortcut); -1: identity form
     int bneck_a;     // index of the block's reduce conv (identity form: the step itself)
+    bool xexp;       // CONV (3x3): the block's expand conv (op i + 1: 1x1 + residual + ReLU) runs in the same launch on the LDS-resident tile (conv3x3_expand_rb.hip)
     bool kcat;       // CONV: expand conv that also computes its projection shortcut (Op::kcat_ds, whose own step is skipped)
     bool direct;     // INPUT + its only consumer, the ResNet stem conv: the conv reads the caller's fp32 NCHW image itself when no resize is asked (conv_stem_pair_kernel)
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
@@ -219,7 +221,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; plan.steps[i].xexp = false; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -470,6 +472,29 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         plan.steps[i + 1].skip = true; plan.steps[i + 2].skip = true; plan.steps[i + 3].skip = true;
     }
 
+    // ---- pass 2c'' (fp16 mode): Bottlenecks that did not fuse as a whole (MID = 256: ResNet-101 layer3): 3x3 conv + expand conv + residual as one launch; the
+    // 3x3's output tensor has no other consumer and is never allocated
+    const char* xexp_env = getenv("GDT_CONV_XEXP");                  // 0: off (read when a net plans a geometry: A/B inside one process)
+    for (int i = 0; i + 1 < nops && !net->precision && !(xexp_env && atoi(xexp_env) == 0); ++i) {
+        const Op &b = ops[i], &c = ops[i + 1];
+        if (b.kind != OP_CONV || c.kind != OP_CONV) continue;
+        auto plain = [&](const Op& o) { return !o.cd.transposed && !o.cd.out_f32_nchw && !o.rowsplit && o.stats_for < 0 && o.cd.stride == 1 && o.phases.size() == 1 && o.phases[0].has_frag && o.has_bias; };
+        if (!plain(b) || !plain(c)) continue;
+        if (b.cd.kh != 3 || b.cd.kw != 3 || b.cd.pad != 1 || b.cd.pad_reflect || !b.cd.relu || b.res >= 0) continue;
+        if (c.cd.kh != 1 || c.cd.kw != 1 || c.cd.pad != 0 || !c.cd.relu || c.in != b.out || c.res < 0 || c.kcat_ds >= 0 || !c.has_bias_frag) continue;
+        if (consumers[b.out] != 1) continue;
+        bool folded = false;
+        for (int k = i; k < i + 2; ++k) folded = folded || plan.steps[k].norm_from >= 0 || plan.steps[k].pool_into >= 0 || plan.steps[k].skip || plan.steps[k].bneck;
+        if (folded) continue;
+        if (b.cd.cin != 256 || b.cin_pad != 256 || b.cd.cout != 256 || b.cout_pad != 256 || c.cd.cin != 256 || c.cout_pad != c.cd.cout) continue;
+        ConvLaunch d{};
+        conv_geometry(net, b, b.phases[0], N, T[b.in], d);
+        d.w_frag = (const f16*)net; d.x_w_frag = (const f16*)net; d.bias = (const float*)net; d.x_bias = (const f16*)net;        // non-null markers only
+        d.res = (const f16*)net; d.out = (f16*)net; d.x_cout = c.cd.cout; d.relu = 1;
+        if (!gdt_conv3x3_expand_eligible(d)) continue;
+        plan.steps[i].xexp = true; plan.steps[i + 1].skip = true;
+    }
+
     // ---- pass 2d (fp16 mode): projection shortcut folded into the expand conv (K-concatenated 1x1, conv1x1_rb.hip) where the block did not fuse as a whole
     for (int i = 0; i < nops && !net->precision; ++i) {
         const Op& c = ops[i];
@@ -541,6 +566,12 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
                 if (st.skip) break;                           // (fused Bottleneck: done by the block's first conv)
                 if (st.bneck) {                               // the launch writes the block output; r and t (and the projected shortcut) never exist
                     Tensor& t = T[ops[i + (st.bneck_ds >= 0 ? 3 : 2)].out];
+                    t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
+                    t.off = arena.alloc(t.bytes);
+                    break;
+                }
+                if (st.xexp) {                                // the launch writes the expand conv's output; the 3x3's own output never exists
+                    Tensor& t = T[ops[i + 1].out];
                     t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
                     t.off = arena.alloc(t.bytes);
                     break;
@@ -840,6 +871,18 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         std::copy(shift.begin(), shift.end(), bp.begin());
         o.bias_off = net->blob_append(bp.data(), bp.size() * sizeof(float));
         o.has_bias = true;
+        if (!net->precision && cd.kh == 1 && cd.kw == 1 && cd.cin == 256 && o.cout_pad % 256 == 0) {
+            // conv3x3_expand_rb.hip adds the expand conv's bias as one more k-step of its GEMM: per 32-channel block a weight fragment whose lane
+            // (channel, fh = 0) holds { fp16(b), fp16(b - fp16(b)), 0 .. } (the pixel operand of that step is { 1, 1, 0 .. })
+            std::vector<f16> bf((size_t)o.cout_pad / 32 * 512, (f16)0.f);
+            for (int c = 0; c < o.cout_pad; ++c) {
+                const f16 hi = (f16)bp[c];
+                bf[((size_t)(c / 32) * 64 + (c & 31)) * 8] = hi;
+                bf[((size_t)(c / 32) * 64 + (c & 31)) * 8 + 1] = (f16)(bp[c] - (float)hi);
+            }
+            o.bias_frag_off = net->blob_append(bf.data(), bf.size() * sizeof(f16));
+            o.has_bias_frag = true;
+        }
     }
 
     auto pack = [&](PackedPhase& ph, auto&& wget) {   // wget(cout, c, tap) -> float
@@ -1449,6 +1492,28 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         rc = gdt_launch_conv_stem_pair(d, (const float*)x, oi.in_c, oi.perm, oi.scale, oi.shift, st);
                     }
                     if (net->profiling) net->last_variant[stp.op] = stp.pool_into >= 0 ? 952049 : 951000 + o.phases[0].ntaps;
+                    break;
+                }
+                if (stp.xexp) {                // 3x3 + expand 1x1 + residual of a Bottleneck in one launch (conv3x3_expand_rb.hip)
+                    const Op& oc = net->ops[stp.op + 1];
+                    ConvLaunch d{};
+                    conv_geometry(net, o, o.phases[0], n, ti, d);
+                    d.in = tptr(o.in); d.zeros = zeros; d.relu = 1;
+                    d.w_frag = (const f16*)(net->dev_blob + o.phases[0].w_frag_off);
+                    d.bias = (const float*)(net->dev_blob + o.bias_off);
+                    d.x_w_frag = (const f16*)(net->dev_blob + oc.phases[0].w_frag_off);
+                    d.x_bias = (const f16*)(net->dev_blob + oc.bias_frag_off);          // (the bias as a weight fragment)
+                    d.x_cout = oc.cd.cout;
+                    d.res = tptr(oc.res); d.out = tptr(oc.out);
+                    GDT_REQUIRE(gdt_conv3x3_expand_eligible(d), "planned 3x3 + expand launch is not eligible at run time");
+                    rc = gdt_launch_conv3x3_expand(d, st);
+                    if (net->profiling) {
+                        net->last_variant[stp.op] = 939000 + oc.cd.cout / 8;
+                        net->last_flops[stp.op] += net->last_flops[stp.op + 1]; net->last_flops[stp.op + 1] = 0.0;
+                        // bytes: the 256-channel tensor between the two convs is neither written nor read
+                        const double mid = (double)n * T[o.out].H * T[o.out].W * T[o.out].C * (double)net->esize();
+                        net->last_bytes[stp.op] += net->last_bytes[stp.op + 1] - 2.0 * mid; net->last_bytes[stp.op + 1] = 0.0;
+                    }
                     break;
                 }
                 if (stp.kcat) {                // expand conv + its projection shortcut as one K-concatenated 1x1 GEMM (conv1x1_rb.hip)
