@@ -185,11 +185,13 @@ def conv_roofline(net, x, steps=3, traffic_key=None):
     net.set_profiling(True)
     per = {}
     all_ms = 0.0
+    all_by = 0.0
     for _ in range(steps):
         net.forward(x)
         torch.cuda.synchronize()
         for (kind, variant, ms, fl), by in zip(net.profile(), net.profile_bytes()):
             all_ms += ms
+            all_by += by
             if kind == 1 and fl > 0:          # (convs fused into a preceding launch -- the Bottleneck kernel -- carry no FLOPs of their own)
                 e = per.setdefault(variant, [0.0, 0.0, 0, 0.0])
                 e[0] += ms; e[1] += fl; e[2] += 1; e[3] += by
@@ -201,6 +203,9 @@ def conv_roofline(net, x, steps=3, traffic_key=None):
             "kernel": kernel_name(variant), "launches_per_step": launches // steps,
             "avg_launch_ms": round(tot_ms / max(1, launches), 4), "share_of_step_time": round(tot_ms / max(all_ms, 1e-9), 3),
             "algorithmic_bytes_per_launch": round(tot_by / max(1, launches)),
+            # every profiled op of the forward: the bytes of the tensors it reads / writes once + its weights, over the summed launch time
+            "whole_forward_hbm": {"algorithmic_gb_per_step": round(all_by / steps / 1e9, 3), "achieved_gbps": round(all_by / max(all_ms, 1e-9) / 1e6, 1),
+                                  "frac_of_8tbps": round(all_by / max(all_ms, 1e-9) / 1e6 / 8000.0, 4)},
             "all_conv_kernels": {kernel_name(v): {"ms_per_step": round(e[0] / steps, 3), "tflops": round(e[1] / max(e[0], 1e-9) / 1e9, 1)}
                                  for v, e in sorted(per.items())}}
 
@@ -444,6 +449,12 @@ def main():
         dt2 = timed(step, a.steps, a.warmup, dev, distributed)
         r_dps = n_total * a.steps / dt2
         roof2 = conv_roofline(emb, xe) if rank == 0 else None
+        if roof2 is not None and roof2.get("kernel", "").startswith("conv3x3_expand"):
+            # the dominant launch is half MFMA-bound (3x3), half HBM-bound (expand + residual + store): both views of the same launches
+            roof2["hbm_view"] = {"bound": "hbm", "achieved": round(roof2["algorithmic_bytes_per_launch"] / (roof2["avg_launch_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                 "unit": "GB/s", "frac": round(roof2["algorithmic_bytes_per_launch"] / (roof2["avg_launch_ms"] * 1e-3) / 8e12, 4),
+                                 "note": "algorithmic bytes of one launch (r in, residual in, y out, both weight matrices) / its average duration; the launch's "
+                                         "MFMA phase moves no HBM bytes (DESIGN.md section 4)"}
         if roof2 is not None and roof2.get("kernel", "").startswith("conv1x1"):
             # the Bottleneck 1x1 convs are HBM-bound, not MFMA-bound: algorithmic bytes (fp16 input once, output once, residual once,
             # weights once -- summed by the library over exactly the launches that were timed, gdt_net_profile_read_bytes) over their

@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
-    m = re.search(r"(conv1x1_rb_kernel|conv3x3_halo_c16_kernel|conv_ct_c16_kernel|conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(conv1x1_rb_kernel|conv3x3_expand_rb_kernel|conv_bneck_kernel|conv_stem_pair_pool_kernel|conv3x3_halo_c16_kernel|conv_ct_c16_kernel|conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
         g = re.search(r"(clahe_\w+_kernel|resample_\w+_kernel|reduce_kernel)(<[^>]*>)?", name)      # section-8f rows
         if g:
