@@ -3,7 +3,7 @@
 #   gpurun -- bash tools/gpu_pmc_embedders.sh
 R=$(pwd)
 export TMPDIR=/tmp
-for NET in r101 vgg16; do
+for NET in ${NETS:-r101 vgg16}; do
   OUT=$R/gpurun_out/pmc_$NET
   mkdir -p $OUT
   SCRIPT=$R/tools/r101_forward.py
@@ -13,6 +13,6 @@ for NET in r101 vgg16; do
     i=$((i+1))
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp -d $OUT/p$i --output-format csv -- python3 $SCRIPT 3 > $OUT/p$i.log 2>&1) || echo "pass $i failed" >> $OUT/fail.log
   done
-  python3 $R/profiles/summarise_pmc_sq.py $OUT $R/gpurun_out/r03_pmc_mfma_$NET.json conv3x3_halo_rb_kernel conv1x1_rb_kernel conv_bneck_kernel conv_stem_pair conv3x3_halo_kernel || true
+  python3 $R/profiles/summarise_pmc_sq.py $OUT $R/gpurun_out/${TAG:-r04}_pmc_mfma_$NET.json conv3x3_expand_rb_kernel conv3x3_halo_rb_kernel conv1x1_rb_kernel conv_bneck_kernel conv_stem_pair conv3x3_halo_kernel || true
   rm -rf $OUT/p1 $OUT/p2
 done
