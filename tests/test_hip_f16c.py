@@ -379,6 +379,42 @@ def test_extract_vectors_batches_equal_sizes(cuda_device, tmp_path):
     assert float(torch.nn.functional.cosine_similarity(grouped.t(), loop.t(), dim=1).min()) > 0.999999
 
 
+def test_extract_vectors_many_distinct_sizes_runs_groups_concurrently(cuda_device, tmp_path):
+    """a collection whose sizes hardly repeat (longer side fixed, arbitrary aspect): the groups are one or two images each, and extract_vectors hands them to the
+    network together, eight images in flight (SingleNetwork.forward_list: every pyramid level of every group in ONE forward_many).  Same columns as with concurrent=1 bit for bit
+    (same kernels per forward, own scratch buffer per forward), and as the image-by-image loop to 5e-5; forward_list == [net(x) for x] bitwise."""
+    import pickle
+    import hubconf
+    from gandtr_amd.learning.checkpoints import Checkpoints
+    from gandtr_amd.stages.validate import extract_vectors
+    import gandtr_amd.learning.network as NW
+    base = hubconf.gem_vgg16_cyclegan(pretrained=False, device="cpu")
+    base.model.load_state_dict(synth.vgg16_state(0))
+    sd = base.state_dict()["net"]
+    sd["network_params"]["runtime"]["data"] = {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]]}
+    ck, lw = str(tmp_path / "vgg.pth"), str(tmp_path / "lw.pkl")
+    torch.save(sd, ck)
+    with open(lw, "wb") as f:
+        pickle.dump(synth.whitening_state(0, 512), f)
+    runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": lw, "dimensions": None}, "1_cirmultiscale": {"scales": True}}}}
+    net = NW.initialize_network(None, cuda_device, Checkpoints.load_network(ck), runtime).eval()
+    shorts = [80, 88, 96, 104, 112, 120, 128]
+    sizes = [((128, shorts[i % 7]) if i % 3 else (shorts[(2 * i) % 7], 128)) for i in range(22)]
+    imgs = [synth.synth_input(300 + i, (3,) + sz) for i, sz in enumerate(sizes)]
+    assert len(set(sizes)) >= 12
+    one = extract_vectors(net, imgs, cuda_device, concurrent=1)
+    four = extract_vectors(net, imgs, cuda_device)                       # default: small groups together, eight images in flight
+    loop = extract_vectors(net, imgs, cuda_device, batched=False)
+    assert torch.equal(one, four) and four.shape == (512, 22)
+    assert float((four - loop).abs().max()) < 5e-5
+    xs = [im.unsqueeze(0) for im in imgs[:5]]
+    with torch.no_grad():
+        listed = net.forward_list(xs)
+        for x, y in zip(xs, listed):
+            assert torch.equal(net(x), y)
+
+
+
 def test_fused_statistics_with_an_odd_number_of_128_row_records(cuda_device):
     """InstanceNorm statistics from a conv epilogue whose 256-row tiles do not divide the layer (N*OH*OW = 128 * odd): the last tile
     owns ONE record, not two (the slab holds M / 128 records; conv_epilogue.h).  The normalised output must be right and the tensor

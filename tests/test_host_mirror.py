@@ -332,6 +332,10 @@ def test_validate_stage_contract():
     import gandtr_amd.learning as L
     net = L.load_network(copy.deepcopy(emb), "cpu")
     assert extract_vectors(net, [], "cpu").shape == (512, 0)
+    # forward_list == the loop over forward, on the CPU too (there the model's forward_many is the plain loop); generators have no forward_many: plain loop
+    xs = [d.unsqueeze(0) for d in db[:3]]
+    for a, b in zip(net.forward_list(xs), [net(x) for x in xs]):
+        assert torch.equal(a, b)
     # equal-size grouping (one forward per group of same-size images) == the reference's image-by-image loop, input order kept
     net.model.load_state_dict(synth.vgg16_state(0))
     loop = extract_vectors(net, db, "cpu", batched=False)

@@ -17,9 +17,18 @@ with tempfile.TemporaryDirectory() as tmp:
         sizes.append((1024, s) if rng.rand() < 0.7 else (s, 1024))
     imgs = [synth.synth_input(500 + i, (3,) + sz).to(dev) for i, sz in enumerate(sizes)]
     print("distinct sizes:", len(set(sizes)))
-    for mode in (False, True):
-        extract_vectors(net, imgs[:8], dev, batched=mode)
+    for label, kw in (("batch-1 loop", {"batched": False}), ("equal sizes batched, one group at a time", {"concurrent": 1}), ("equal sizes batched, small groups together (8 images in flight)", {})):
+        extract_vectors(net, imgs, dev, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        v = extract_vectors(net, imgs, dev, batched=mode)
+        v = extract_vectors(net, imgs, dev, **kw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print("batched" if mode else "batch-1 loop", "%.1f desc/s (%.1f ms per image)" % (len(imgs) / dt, dt / len(imgs) * 1e3))
+        print(label, "%.1f desc/s (%.1f ms per image)" % (len(imgs) / dt, dt / len(imgs) * 1e3))
+    # every size different: nothing to batch
+    uniq = [synth.synth_input(900 + i, (3, 1024, 600 + 8 * i)).to(dev) for i in range(48)]
+    for label, kw in (("all sizes distinct: batch-1 loop", {"batched": False}), ("all sizes distinct: two forwards in flight", {"concurrent": 2}), ("all sizes distinct: four forwards in flight", {"concurrent": 4}),
+                      ("all sizes distinct: eight forwards in flight (default)", {})):
+        extract_vectors(net, uniq, dev, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        v = extract_vectors(net, uniq, dev, **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(label, "%.1f desc/s (%.1f ms per image)" % (len(uniq) / dt, dt / len(uniq) * 1e3))
