@@ -4,11 +4,15 @@ The reference body wires datasets (DataLoader with 6 workers), output sinks and 
 ``out = network(indata)``; those subsystems are out of scope, so this mirror accepts in-memory
 inputs: ``data[0]`` is a sequence of image tensors (C x H x W or 1 x C x H x W).  Per item it calls ``network(indata)`` under
 ``torch.no_grad()`` exactly like the reference (batch size 1, the only mode the reference's wrappers support) and collects the
-outputs according to ``params["output"]["inference"]["name"]``:
+outputs according to ``params["output"]["inference"]["name"]``.  On a HIP device items of EQUAL size are grouped and go through the network as one batch
+(at most ``GANDTR_INFER_BATCH`` = 64 items; 0 / 1 = the reference's item-by-item loop): no op of either model family crosses images (InstanceNorm is per image,
+BatchNorm is in eval mode, GeM / L2N / whitening per image), so the outputs are those of the loop -- in the input's order -- while the conv kernels run at 6-9x
+the batch-1 rate.  Outputs:
     "embedding" -> one (N x D) float32 numpy array   (EmbeddingOutput, mdir/components/data/output.py:118-156)
     "rgb"       -> a list of H x W x 3 float arrays in [0, 1] (un-normalised with the network's mean_std; RgbImageSaver :75-84)
 """
 import copy
+import os
 import time
 
 import numpy as np
@@ -29,6 +33,9 @@ def infer(params, data):
         raise KeyError(kind)
     mean_std = network.network_params.runtime.get("data", {}).get("mean_std")
     outputs, t0 = [], time.time()
+    max_batch = int(os.environ.get("GANDTR_INFER_BATCH", "64")) if device.type == "cuda" else 1
+    if max_batch > 1 and "forward" not in params:
+        return _infer_grouped(network, data[0], kind, mean_std, device, max_batch, t0)
     with torch.no_grad():
         forward = getattr(network, params["forward"]["method"]) if "forward" in params else network
         for indata in data[0]:
@@ -50,3 +57,35 @@ def infer(params, data):
     if kind == "embedding":
         return (metadata, np.stack(outputs))
     return (metadata, outputs)
+
+
+def _infer_grouped(network, items, kind, mean_std, device, max_batch, t0):
+    """equal-size items as batches, outputs in input order (see the module docstring)"""
+    from .validate import extract_vectors
+    xs = []
+    for indata in items:
+        x = torch.as_tensor(indata)
+        xs.append(x.unsqueeze(0) if x.dim() == 3 else x)
+    if kind == "embedding":
+        vecs = extract_vectors(network, xs, device, batched=True, max_batch=min(max_batch, 32))        # D x N on the device
+        return ({"stats": {"items": len(xs), "seconds": time.time() - t0}}, vecs.t().contiguous().cpu().numpy())
+    outputs = [None] * len(xs)
+    jobs, groups = [], {}
+    for i, x in enumerate(xs):
+        if x.shape[0] != 1:
+            jobs.append([i])                                # an item that is a batch already: the loop takes its first image, so does this path
+        else:
+            groups.setdefault(tuple(x.shape), []).append(i)
+    for idx in groups.values():
+        jobs.extend(idx[lo:lo + max_batch] for lo in range(0, len(idx), max_batch))
+    mean = torch.tensor(mean_std[0], device=device)[:, None, None] if mean_std is not None else None
+    std = torch.tensor(mean_std[1], device=device)[:, None, None] if mean_std is not None else None
+    with torch.no_grad():
+        for part in jobs:
+            out = network(torch.cat([xs[i] for i in part], 0) if len(part) > 1 else xs[part[0]]).detach().float()
+            if mean is not None:
+                out = out * std + mean
+            img = out.clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+            for j, i in enumerate(part):
+                outputs[i] = img[j]
+    return ({"stats": {"items": len(outputs), "seconds": time.time() - t0}}, outputs)

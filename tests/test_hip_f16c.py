@@ -538,3 +538,26 @@ def test_rank_images_on_jpeg_files(cuda_device, tmp_path):
     meta, ranks, scores = rank_images(params, (paths, [buf.getvalue()], {"image_size": 160}))
     assert ranks.shape == (6, 1) and ranks[0, 0] == 4 and scores[4, 0] > 0.97
     assert meta["eval"]["database"] == 6 and meta["eval"]["queries"] == 1
+
+
+def test_infer_stage_groups_equal_sizes_on_the_device(cuda_device, tmp_path, monkeypatch):
+    """the `infer` stage on a HIP device: items of equal size go through the generator as one batch (mdir/stages/infer.py:17-66 runs them one by one; no op of the
+    generator crosses images) -- same pictures as the item-by-item loop (GANDTR_INFER_BATCH=1) to the f16c mode's own tolerance, in the input's order"""
+    import hubconf
+    from gandtr_amd.stages import FUNCTIONS
+    infer = FUNCTIONS["mdir.stages.infer.infer"]
+    gen = hubconf.cyclegan(pretrained=False, device="cpu")
+    gen.model.load_state_dict(synth.generator_state(0, "instance"))
+    sd = gen.state_dict()["net"]
+    sd["network_params"]["runtime"]["data"] = {"transforms": "pil2np | totensor | normalize", "mean_std": [[0.5] * 3, [0.5] * 3]}
+    ck = tmp_path / "gen.pth"
+    torch.save(sd, ck)
+    params = {"network": {"path": str(ck), "runtime": {"wrappers": ""}}, "output": {"inference": {"name": "rgb"}}}
+    items = [synth.synth_input(700 + i, (3, 64, 64) if i % 3 else (3, 64, 96), 1.0) for i in range(11)]
+    meta, grouped = infer(params, (items,))
+    monkeypatch.setenv("GANDTR_INFER_BATCH", "1")
+    _, loop = infer(params, (items,))
+    assert meta["stats"]["items"] == 11 and len(grouped) == len(loop) == 11
+    for g, l, x in zip(grouped, loop, items):
+        assert g.shape == l.shape == (x.shape[1], x.shape[2], 3)
+        assert float(np.abs(g - l).max()) < 2e-3          # pictures in [0, 1]; batch 1 and batch 4-7 pick other kernel variants (f16x3 generic vs compensated patch kernels)

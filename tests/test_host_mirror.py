@@ -291,6 +291,18 @@ def test_infer_stage_contract(tmp_path):
                        ([synth.synth_input(30, (3, 32, 32), 1.0)],))
     assert len(pics) == 1 and pics[0].shape == (32, 32, 3) and 0.0 <= pics[0].min() and pics[0].max() <= 1.0
     assert infer({"network": emb, "output": {"inference": {"name": "embedding"}}}, ([],)) == ({"status": "skipped"},)
+    # the HIP device's grouped path (equal sizes as one batch, outputs in input order), exercised here on the CPU against the item-by-item loop
+    from gandtr_amd.stages.infer import _infer_grouped
+    import gandtr_amd.learning as L
+    import copy
+    net = L.load_network({"path": str(ck), "runtime": {"wrappers": ""}}, "cpu").eval()
+    mixed = [synth.synth_input(60 + i, (3, 32, 32) if i % 2 else (3, 32, 48), 1.0) for i in range(5)]
+    _, loop = infer({"network": {"path": str(ck), "runtime": {"wrappers": ""}}, "output": {"inference": {"name": "rgb"}}}, (mixed,))
+    _, grouped = _infer_grouped(net, mixed, "rgb", [[0.5] * 3, [0.5] * 3], torch.device("cpu"), 4, 0.0)
+    assert len(grouped) == 5 and all(g.shape == l.shape and np.abs(g - l).max() < 1e-5 for g, l in zip(grouped, loop))
+    enet = L.load_network(copy.deepcopy(emb), "cpu").eval()
+    _, gv = _infer_grouped(enet, imgs, "embedding", None, torch.device("cpu"), 4, 0.0)
+    assert gv.shape == (3, 512) and np.allclose(np.linalg.norm(gv, axis=1), 1.0, atol=1e-4)
 
 
 def test_validate_stage_contract():
