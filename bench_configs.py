@@ -178,6 +178,17 @@ def self_launch(argv, gpus):
     return subprocess.run(cmd, env=env, check=False).returncode
 
 
+def _roofline_of(model, x):
+    """bench.py's live per-kernel roofline object (HIP events around every op inside the library) for the engine net a hub model has built for its last forward"""
+    import bench
+    nets = [v for k, v in getattr(model, "_hip_cache", {}).items() if k != "__stamp__"]
+    if len(nets) > 1:                                   # (the generator of c2 also ran in the opt-in fp16 mode: report the default mode's net)
+        nets = [n for n in nets if getattr(n, "precision", None) == "f16c"]
+    if len(nets) != 1:
+        return None
+    return bench.conv_roofline(nets[0], x, steps=2)
+
+
 def main():
     dev = torch.device("cuda:0")
     out = {}
@@ -195,7 +206,8 @@ def main():
         net.model.load_state_dict(synth.vgg16_state(0))
         x = synth.synth_input(2, (32, 3, 1024, 1024)).to(dev)
         r, ms = rate(lambda: net(x), 32, steps=4, warmup=1)
-        out["c1_gem_vgg16_32x1024"] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * 641.4 / 1e3, 1)}
+        out["c1_gem_vgg16_32x1024"] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * 641.4 / 1e3, 1),
+                                       "roofline": _roofline_of(net.model, x)}
         del net, x
         torch.cuda.empty_cache()
 
@@ -222,6 +234,7 @@ def main():
         # regression guard (round 1 saw this leg at 4.2 -> 6.5 ms with no kernel change; root cause in DESIGN.md section 6): the HED leg
         # (40.1 GFLOP / image, wrappers folded into its input pack) must stay under 4.5 ms per 64-image batch
         out["c2_hedngan_plus_hed_64x256"]["hed_leg_within_4p5_ms"] = bool(msh < 4.5)
+        out["c2_hedngan_plus_hed_64x256"]["roofline_generator"] = _roofline_of(gen.model, x)
         del y
         del gen, hed, x
         torch.cuda.empty_cache()

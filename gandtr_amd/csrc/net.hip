@@ -1355,11 +1355,13 @@ static double op_bytes(const gdt_net* net, const Op& o, int n) {
     if (o.kind != OP_CONV) return 0.0;
     const double es = (double)net->esize();
     const Tensor& ti = net->tensors[o.in];
-    const Tensor& to = net->tensors[o.out];
+    // (output geometry from the conv itself: a conv that writes a caller-facing fp32 NCHW slot has no internal output tensor)
+    const double oh = conv_out_dim(o.cd, ti.H, o.cd.kh), ow = conv_out_dim(o.cd, ti.W, o.cd.kw);
+    const double out_b = (double)n * oh * ow * o.cd.cout * (o.cd.out_f32_nchw ? 4.0 : es);
     double in_px = (double)n * ti.H * ti.W;
-    if (!o.cd.transposed && o.cd.kh == 1 && o.cd.kw == 1 && o.cd.stride > 1) in_px = (double)n * to.H * to.W;
-    double b = in_px * ti.C * es + (double)n * to.H * to.W * to.C * es;
-    if (o.res >= 0) b += (double)n * to.H * to.W * to.C * es;
+    if (!o.cd.transposed && o.cd.kh == 1 && o.cd.kw == 1 && o.cd.stride > 1) in_px = (double)n * oh * ow;
+    double b = in_px * ti.C * es + out_b;
+    if (o.res >= 0) b += out_b;
     b += (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw * sizeof(f16);
     return b;
 }
