@@ -28,11 +28,11 @@ class IngestItem(ctypes.Structure):
 
 class JpegInfo(ctypes.Structure):
     """struct gdt_jpeg_info (include/gandtr_hip.h)."""
-    _fields_ = [("width", c_int), ("height", c_int), ("ncomp", c_int), ("hs", c_int * 3), ("vs", c_int * 3), ("tq", c_int * 3),
-                ("td", c_int * 3), ("ta", c_int * 3), ("restart_interval", c_int), ("mcus_x", c_int), ("mcus_y", c_int),
+    _fields_ = [("width", c_int), ("height", c_int), ("ncomp", c_int), ("hs", c_int * 4), ("vs", c_int * 4), ("tq", c_int * 4),
+                ("td", c_int * 4), ("ta", c_int * 4), ("restart_interval", c_int), ("mcus_x", c_int), ("mcus_y", c_int),
                 ("blocks_per_mcu", c_int), ("nsegments", c_int), ("scan_offset", ctypes.c_ulonglong),
                 ("scan_capacity", ctypes.c_ulonglong), ("quant", (ctypes.c_ushort * 64) * 4), ("huff_bits", (ctypes.c_ubyte * 17) * 4),
-                ("huff_vals", (ctypes.c_ubyte * 256) * 4), ("progressive", c_int), ("comp_id", c_int * 3)]
+                ("huff_vals", (ctypes.c_ubyte * 256) * 4), ("progressive", c_int), ("comp_id", c_int * 4), ("adobe_transform", c_int)]
 
 
 class JpegItem(ctypes.Structure):

@@ -4,7 +4,9 @@
 // genericdataset.py:66-102).  The reference decodes through Pillow, i.e. libjpeg-turbo with its defaults; the result here is
 // bit-identical to that: the "islow" integer inverse DCT (LL&M, 13-bit constants, 2 extra bits after the column pass), "fancy" triangle
 // upsampling of 4:2:2 / 4:2:0 chroma (replication when the chroma plane is at most two samples wide), the 16-bit fixed-point
-// YCbCr -> RGB conversion.  The algorithms are restated from the JPEG standard (ITU T.81 Annex F: Huffman procedures) and from the
+// YCbCr -> RGB conversion; four-component files (CMYK as Adobe transform 0 / no Adobe marker, YCCK as transform 2; first component at 1 x 1, 2 x 1 or 2 x 2,
+// the others at 1 x 1) through the library's YCCK -> CMYK step, the inversion Pillow's plugin applies to every CMYK JPEG and convert('RGB')'s
+// nk - MULDIV255(c, nk) arithmetic.  The algorithms are restated from the JPEG standard (ITU T.81 Annex F: Huffman procedures) and from the
 // published arithmetic of those libjpeg routines; no source of either library is in this tree.
 //
 // What makes it a device decoder rather than a device back end is the entropy decoder.  A Huffman-coded scan is one serial bit
@@ -53,12 +55,13 @@ const unsigned char h_nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25,
 // ------------------------------------------------------------------------------------------------ device-side descriptors
 struct DImg {
     int width, height, ncomp, B;                   // B: blocks per MCU
-    int mcus_x, mcus_y, hs0, vs0;                  // luma sampling factors (chroma is 1 x 1)
-    int pitch[3], dw[3], dh[3];                    // plane pitch in bytes; real (un-padded) sample columns / rows of the component
-    int tdc[3], tac[3];                            // Huffman table numbers (0 / 1) per component
-    unsigned total_blocks, first_seg, nseg, pad0;
+    int mcus_x, mcus_y, hs0, vs0;                  // sampling factors of component 0 (the others are 1 x 1)
+    int pitch[4], dw[4], dh[4];                    // plane pitch in bytes; real (un-padded) sample columns / rows of the component
+    int tdc[4], tac[4];                            // Huffman table numbers (0 / 1) per component
+    unsigned total_blocks, first_seg, nseg;
+    int ycck;                                      // four components: 1 = YCCK (the first three go through the YCbCr -> RGB tables first), 0 = CMYK
     unsigned long long coef_off;                   // int16 elements from the coefficient base
-    unsigned long long plane_off[3];               // bytes from the plane base
+    unsigned long long plane_off[4];               // bytes from the plane base
     const unsigned char* scan;
     unsigned char* dst;
 };
@@ -72,7 +75,7 @@ struct DTab {
     int maxcode[4][18];                            // largest code of each length (-1: none)
     int valoff[4][18];                             // index of the symbol of code c of length l = c + valoff[l]
     unsigned char vals[4][256];
-    unsigned short quant[3][64];                   // per component, natural order
+    unsigned short quant[4][64];                   // per component, natural order
 };
 
 struct HState { unsigned p; int b, z; };
@@ -88,7 +91,7 @@ template <bool WRITE, typename Tab>
 __device__ __forceinline__ unsigned decode_span(const DImg& im, const Tab& tb, unsigned limit, HState& s, short* __restrict__ coef, unsigned g, unsigned g_end) {
     const unsigned* __restrict__ words = (const unsigned*)im.scan;
     const int nY = im.ncomp == 1 ? 1 : im.hs0 * im.vs0, B = im.B;
-    const unsigned tsel = (unsigned)(im.tdc[0] | (im.tdc[1] << 1) | (im.tdc[2] << 2) | (im.tac[0] << 3) | (im.tac[1] << 4) | (im.tac[2] << 5));
+    const unsigned tsel = (unsigned)(im.tdc[0] | (im.tdc[1] << 1) | (im.tdc[2] << 2) | (im.tdc[3] << 3) | (im.tac[0] << 4) | (im.tac[1] << 5) | (im.tac[2] << 6) | (im.tac[3] << 7));
     unsigned done = 0, p = s.p;
     int b = s.b, z = s.z;
     unsigned next = (p >> 5) + 2;
@@ -98,7 +101,7 @@ __device__ __forceinline__ unsigned decode_span(const DImg& im, const Tab& tb, u
     while (p < limit) {
         const unsigned w = (unsigned)(buf >> 32);
         const int c = b < nY ? 0 : b - nY + 1;
-        const int t = z == 0 ? (int)((tsel >> c) & 1u) : 2 + (int)((tsel >> (3 + c)) & 1u);
+        const int t = z == 0 ? (int)((tsel >> c) & 1u) : 2 + (int)((tsel >> (4 + c)) & 1u);
         const unsigned v = w >> 16;
         const unsigned lk = tb.look[t][v >> 7];
         int len, sym;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(const DImg* __restrict__ 
     const unsigned mcu = g / (unsigned)im.B, b = g - mcu * (unsigned)im.B;
     const unsigned nY = im.ncomp == 1 ? 1u : (unsigned)(im.hs0 * im.vs0);
     const int c = b < nY ? 0 : (int)(b - nY + 1);
-    const int hs = c == 0 && im.ncomp == 3 ? im.hs0 : 1, vs = c == 0 && im.ncomp == 3 ? im.vs0 : 1;
+    const int hs = c == 0 && im.ncomp >= 3 ? im.hs0 : 1, vs = c == 0 && im.ncomp >= 3 ? im.vs0 : 1;
     const int bx = (int)(mcu % (unsigned)im.mcus_x) * hs + (c == 0 ? (int)(b % (unsigned)hs) : 0);
     const int by = (int)(mcu / (unsigned)im.mcus_x) * vs + (c == 0 ? (int)(b / (unsigned)hs) : 0);
     const short* __restrict__ cf = coef_base + im.coef_off + (size_t)g * 64;
@@ -368,6 +371,23 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const DImg* __restrict_
         g = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
         b = yy + ((116130 * cb + 32768) >> 16);
         r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+    } else if (im.ncomp == 4) {
+        // Four components.  The library's output is CMYK: the samples as stored (Adobe transform 0 / no Adobe marker) or, for YCCK, (255 - R, 255 - G, 255 - B, K)
+        // of the first three components' YCbCr -> RGB (jdcolor.c ycck_cmyk_convert).  Pillow's plugin takes every CMYK JPEG as inverted ("CMYK;I": P = 255 - S) and
+        // convert('RGB') computes  nk = 255 - P_k,  out = clip(nk - MULDIV255(P_c, nk))  with  MULDIV255(a, b) = ((t = a * b + 128) + (t >> 8)) >> 8
+        int s0 = yy;
+        int s1 = chroma_at(im, plane_base + im.plane_off[1], 1, x, y), s2 = chroma_at(im, plane_base + im.plane_off[2], 2, x, y);
+        const int nk = chroma_at(im, plane_base + im.plane_off[3], 3, x, y);
+        if (im.ycck) {
+            const int cb = s1 - 128, cr = s2 - 128;
+            const int rr = min(max(yy + ((91881 * cr + 32768) >> 16), 0), 255), gg = min(max(yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16), 0), 255);
+            const int bb = min(max(yy + ((116130 * cb + 32768) >> 16), 0), 255);
+            s0 = 255 - rr; s1 = 255 - gg; s2 = 255 - bb;
+        }
+        auto muldiv255 = [](int a, int bq) -> int { const int t = a * bq + 128; return ((t >> 8) + t) >> 8; };
+        r = min(max(nk - muldiv255(255 - s0, nk), 0), 255);
+        g = min(max(nk - muldiv255(255 - s1, nk), 0), 255);
+        b = min(max(nk - muldiv255(255 - s2, nk), 0), 255);
     }
     unsigned char* o = im.dst + (size_t)i * 3;
     o[0] = (unsigned char)r; o[1] = (unsigned char)g; o[2] = (unsigned char)b;
@@ -427,7 +447,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
     if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail("not a JPEG file (no SOI marker)");
     Reader r{f, n, 2};
     bool have_frame = false, have_q[4] = {false, false, false, false}, have_h[4] = {false, false, false, false}, jfif = false, adobe = false;
-    int adobe_transform = -1, comp_id[3] = {0, 0, 0};
+    int adobe_transform = -1, comp_id[4] = {0, 0, 0, 0};
     for (;;) {
         if (!r.has(2)) return fail("truncated before the scan");
         if (r.u8() != 0xFF) return fail("marker expected");
@@ -446,7 +466,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
             const int prec = r.u8();
             info->height = r.u16(); info->width = r.u16(); info->ncomp = r.u8();
             if (prec != 8) return fail("only 8-bit samples are decoded on the device");
-            if (info->ncomp != 1 && info->ncomp != 3) return fail("only grayscale and three-component files are decoded on the device");
+            if (info->ncomp != 1 && info->ncomp != 3 && info->ncomp != 4) return fail("only files of one, three or four components are decoded on the device");
             if (info->width <= 0 || info->height <= 0) return fail("empty image (or height deferred to a DNL marker)");
             if (len != 8 + 3 * info->ncomp) return fail("bad frame header");
             for (int c = 0; c < info->ncomp; ++c) {
@@ -530,17 +550,25 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
         const bool chroma_ok = info->hs[1] == 1 && info->vs[1] == 1 && info->hs[2] == 1 && info->vs[2] == 1;
         const bool luma_ok = (info->hs[0] == 1 && info->vs[0] == 1) || (info->hs[0] == 2 && info->vs[0] == 1) || (info->hs[0] == 2 && info->vs[0] == 2);
         if (!chroma_ok || !luma_ok) return fail("sampling factors other than 4:4:4, 4:2:2 and 4:2:0 are not decoded on the device");
+    } else if (info->ncomp == 4) {
+        // CMYK (Adobe transform 0, or no Adobe marker: the library's guess for four components) or YCCK (transform 2)
+        if (adobe && adobe_transform != 0 && adobe_transform != 2) return fail("four-component file with an unknown Adobe transform");
+        info->adobe_transform = adobe && adobe_transform == 2 ? 2 : 0;
+        bool rest_ok = true;
+        for (int c = 1; c < 4; ++c) rest_ok = rest_ok && info->hs[c] == 1 && info->vs[c] == 1;
+        const bool first_ok = (info->hs[0] == 1 && info->vs[0] == 1) || (info->hs[0] == 2 && info->vs[0] == 1) || (info->hs[0] == 2 && info->vs[0] == 2);
+        if (!rest_ok || !first_ok) return fail("four-component files are decoded on the device with components 2-4 at 1 x 1 and the first at 1 x 1, 2 x 1 or 2 x 2");
     } else {
         info->hs[0] = 1; info->vs[0] = 1;                   // a single-component scan is never interleaved: one block per MCU
     }
     const int hmax = info->hs[0], vmax = info->vs[0];
     info->mcus_x = (info->width + 8 * hmax - 1) / (8 * hmax);
     info->mcus_y = (info->height + 8 * vmax - 1) / (8 * vmax);
-    info->blocks_per_mcu = info->ncomp == 1 ? 1 : hmax * vmax + 2;
+    info->blocks_per_mcu = info->ncomp == 1 ? 1 : hmax * vmax + info->ncomp - 1;
     if ((long long)info->mcus_x * info->mcus_y * info->blocks_per_mcu >= (1LL << 26)) return fail("image too large");
     info->scan_offset = r.pos;
     if (info->progressive) {                  // (the scans are walked -- and a truncated file refused -- by gdt_jpeg_progressive_coefficients)
-        for (int c = 0; c < 3; ++c) info->comp_id[c] = comp_id[c];
+        for (int c = 0; c < 4; ++c) info->comp_id[c] = comp_id[c];
         info->nsegments = 1; info->scan_capacity = scan_capacity_for(0);
         return GDT_OK;
     }
@@ -597,14 +625,14 @@ int make_plan(const gdt_jpeg_item* items, int n, int mode, Plan& p) {
         const gdt_jpeg_item& it = items[i];
         GDT_REQUIRE(it.info != nullptr && it.seg_off != nullptr, "jpeg: item without info / segment offsets");
         const gdt_jpeg_info& f = *it.info;
-        GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3) && f.width > 0 && f.height > 0 && f.nsegments >= 1 && f.mcus_x > 0 && f.mcus_y > 0,
+        GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3 || f.ncomp == 4) && f.width > 0 && f.height > 0 && f.nsegments >= 1 && f.mcus_x > 0 && f.mcus_y > 0,
                     "jpeg: info was not filled by gdt_jpeg_parse");
         GDT_REQUIRE(!f.progressive, "jpeg: progressive files are decoded through gdt_jpeg_progressive_coefficients + gdt_jpeg_decode_coef_u8_batch");
         GDT_REQUIRE(((uintptr_t)it.scan & 15) == 0, "jpeg: scan buffers must be 16-byte aligned");
         DImg& d = p.imgs[i];
         memset(&d, 0, sizeof(d));
         d.width = f.width; d.height = f.height; d.ncomp = f.ncomp; d.B = f.blocks_per_mcu;
-        d.mcus_x = f.mcus_x; d.mcus_y = f.mcus_y; d.hs0 = f.ncomp == 3 ? f.hs[0] : 1; d.vs0 = f.ncomp == 3 ? f.vs[0] : 1;
+        d.mcus_x = f.mcus_x; d.mcus_y = f.mcus_y; d.hs0 = f.ncomp >= 3 ? f.hs[0] : 1; d.vs0 = f.ncomp >= 3 ? f.vs[0] : 1; d.ycck = f.ncomp == 4 && f.adobe_transform == 2;
         d.total_blocks = (unsigned)((long long)f.mcus_x * f.mcus_y * f.blocks_per_mcu);
         d.coef_off = p.coef_elems;
         p.coef_elems += (size_t)d.total_blocks * 64;
@@ -701,7 +729,7 @@ int run_decode(const gdt_jpeg_item* items, int n, int mode, const Plan& p, char*
         GDT_CHECK_HIP(hipMemsetAsync(d_blk0, 0, (size_t)p.nsub * 4, stream));
     }
     hipLaunchKernelGGL(jpeg_write_kernel, dim3(grid_sub), dim3(256), 0, stream, d_imgs, d_segs, d_tabs, nseg, p.nsub, d_exit, d_blk0, d_coef);
-    hipLaunchKernelGGL(jpeg_dc_kernel, dim3(nseg, 3), dim3(256), 0, stream, d_imgs, d_segs, d_coef);
+    hipLaunchKernelGGL(jpeg_dc_kernel, dim3(nseg, 4), dim3(256), 0, stream, d_imgs, d_segs, d_coef);
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((p.max_blocks + 63u) / 64u, n), dim3(64), 0, stream, d_imgs, d_tabs, d_coef, d_planes);
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((p.max_pixels + 255u) / 256u, n), dim3(256), 0, stream, d_imgs, d_planes);
     GDT_CHECK_HIP(hipGetLastError());
@@ -790,17 +818,17 @@ inline int extend(unsigned v, int s) { return s == 0 ? 0 : ((int)v < (1 << (s - 
 int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info, short* coef) {
     if (!info.progressive || info.scan_offset < 2 || info.scan_offset >= n) return fail("info was not filled by gdt_jpeg_parse for a progressive file");
     const int ncomp = info.ncomp, B = info.blocks_per_mcu;
-    const int hmax = ncomp == 3 ? info.hs[0] : 1, vmax = ncomp == 3 ? info.vs[0] : 1;
+    const int hmax = ncomp >= 3 ? info.hs[0] : 1, vmax = ncomp >= 3 ? info.vs[0] : 1;
     const long long total_blocks = (long long)info.mcus_x * info.mcus_y * B;
     memset(coef, 0, (size_t)total_blocks * 64 * sizeof(short));
     const int nY = ncomp == 1 ? 1 : hmax * vmax;
     // the block grid a NON-interleaved scan of component c covers (its own size, not padded to whole MCUs) and its block -> storage index
-    auto comp_w = [&](int c) { const int hs = (ncomp == 3 && c == 0) ? hmax : 1; return ((info.width * hs + hmax - 1) / hmax + 7) / 8; };
-    auto comp_h = [&](int c) { const int vs = (ncomp == 3 && c == 0) ? vmax : 1; return ((info.height * vs + vmax - 1) / vmax + 7) / 8; };
+    auto comp_w = [&](int c) { const int hs = (ncomp >= 3 && c == 0) ? hmax : 1; return ((info.width * hs + hmax - 1) / hmax + 7) / 8; };
+    auto comp_h = [&](int c) { const int vs = (ncomp >= 3 && c == 0) ? vmax : 1; return ((info.height * vs + vmax - 1) / vmax + 7) / 8; };
     auto block_at = [&](int c, int bx, int by) -> short* {
         long long g;
-        if (ncomp == 3 && c == 0) g = ((long long)(by / vmax) * info.mcus_x + bx / hmax) * B + (by % vmax) * hmax + (bx % hmax);
-        else if (ncomp == 3) g = ((long long)by * info.mcus_x + bx) * B + nY + (c - 1);
+        if (ncomp >= 3 && c == 0) g = ((long long)(by / vmax) * info.mcus_x + bx / hmax) * B + (by % vmax) * hmax + (bx % hmax);
+        else if (ncomp >= 3) g = ((long long)by * info.mcus_x + bx) * B + nY + (c - 1);
         else g = (long long)by * info.mcus_x + bx;
         return coef + g * 64;
     };
@@ -873,7 +901,7 @@ int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info
         if (len < 8) return fail("bad scan header");
         const int ns = f[pos + 2];
         if (ns < 1 || ns > ncomp || len != (size_t)(6 + 2 * ns)) return fail("bad scan header");
-        int sc[3], td[3], ta[3];
+        int sc[4], td[4], ta[4];
         for (int i = 0; i < ns; ++i) {
             const int id = f[pos + 3 + 2 * i], tt = f[pos + 4 + 2 * i];
             int c = -1;
@@ -895,7 +923,7 @@ int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info
         // geometry of the scan: MCUs of the frame (interleaved) or the component's own blocks
         const int sw = interleaved ? info.mcus_x : comp_w(sc[0]), sh = interleaved ? info.mcus_y : comp_h(sc[0]);
         const long long units = (long long)sw * sh;
-        int pred[3] = {0, 0, 0};
+        int pred[4] = {0, 0, 0, 0};
         unsigned eobrun = 0;
         const int p1 = 1 << Al, m1 = -(1 << Al);
         long long until_restart = restart_interval > 0 ? restart_interval : -1;
@@ -909,7 +937,7 @@ int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info
             const int ux = (int)(u % sw), uy = (int)(u / sw);
             for (int i = 0; i < ns; ++i) {
                 const int c = sc[i];
-                const int bw = interleaved && ncomp == 3 && c == 0 ? hmax : 1, bh = interleaved && ncomp == 3 && c == 0 ? vmax : 1;
+                const int bw = interleaved && ncomp >= 3 && c == 0 ? hmax : 1, bh = interleaved && ncomp >= 3 && c == 0 ? vmax : 1;
                 for (int by = 0; by < bh; ++by)
                     for (int bx = 0; bx < bw; ++bx) {
                         short* blk = interleaved ? block_at(c, ux * bw + bx, uy * bh + by) : block_at(c, ux, uy);
@@ -1047,7 +1075,7 @@ int gdt_jpeg_decode_u8_batch(const gdt_jpeg_item* items, int n, int mode, void* 
 
 int gdt_jpeg_progressive_coefficients(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, short* coef) {
     GDT_REQUIRE(file != nullptr && info != nullptr && coef != nullptr, "jpeg: null argument");
-    GDT_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->mcus_x > 0 && info->mcus_y > 0 && info->blocks_per_mcu >= 1, "jpeg: info was not filled by gdt_jpeg_parse");
+    GDT_REQUIRE((info->ncomp == 1 || info->ncomp == 3 || info->ncomp == 4) && info->mcus_x > 0 && info->mcus_y > 0 && info->blocks_per_mcu >= 1, "jpeg: info was not filled by gdt_jpeg_parse");
     return progressive_impl(file, nbytes, *info, coef);
 }
 
@@ -1063,12 +1091,12 @@ static int plan_coef(const gdt_jpeg_info* infos, int n, const size_t* coef_off, 
     p.imgs.resize(n); p.tabs.resize(n);
     for (int i = 0; i < n; ++i) {
         const gdt_jpeg_info& f = infos[i];
-        GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3) && f.width > 0 && f.height > 0 && f.mcus_x > 0 && f.mcus_y > 0 && f.blocks_per_mcu >= 1,
+        GDT_REQUIRE((f.ncomp == 1 || f.ncomp == 3 || f.ncomp == 4) && f.width > 0 && f.height > 0 && f.mcus_x > 0 && f.mcus_y > 0 && f.blocks_per_mcu >= 1,
                     "jpeg: info was not filled by gdt_jpeg_parse");
         DImg& d = p.imgs[i];
         memset(&d, 0, sizeof(d));
         d.width = f.width; d.height = f.height; d.ncomp = f.ncomp; d.B = f.blocks_per_mcu;
-        d.mcus_x = f.mcus_x; d.mcus_y = f.mcus_y; d.hs0 = f.ncomp == 3 ? f.hs[0] : 1; d.vs0 = f.ncomp == 3 ? f.vs[0] : 1;
+        d.mcus_x = f.mcus_x; d.mcus_y = f.mcus_y; d.hs0 = f.ncomp >= 3 ? f.hs[0] : 1; d.vs0 = f.ncomp >= 3 ? f.vs[0] : 1; d.ycck = f.ncomp == 4 && f.adobe_transform == 2;
         d.total_blocks = (unsigned)((long long)f.mcus_x * f.mcus_y * f.blocks_per_mcu);
         d.coef_off = coef_off ? coef_off[i] : 0;
         for (int c = 0; c < f.ncomp; ++c) {

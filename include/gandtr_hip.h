@@ -258,8 +258,8 @@ int gdt_ingest_resize_u8_batch(const gdt_ingest_item* items, int n, int c, const
  * run per block / per pixel.  mode = 1 decodes every interval with ONE thread instead (the checker of the parallel decoder).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct gdt_jpeg_info {
-    int width, height, ncomp;                 /* ncomp 1 (grayscale) or 3 (YCbCr) */
-    int hs[3], vs[3], tq[3], td[3], ta[3];     /* per component: sampling factors, quantisation / DC / AC table numbers */
+    int width, height, ncomp;                 /* ncomp 1 (grayscale), 3 (YCbCr) or 4 (CMYK / YCCK, see adobe_transform) */
+    int hs[4], vs[4], tq[4], td[4], ta[4];     /* per component: sampling factors, quantisation / DC / AC table numbers */
     int restart_interval;                      /* in MCUs, 0 = none */
     int mcus_x, mcus_y, blocks_per_mcu;
     int nsegments;                             /* restart intervals in the scan (1 without restart markers) */
@@ -270,7 +270,10 @@ typedef struct gdt_jpeg_info {
     unsigned char huff_vals[4][256];
     int progressive;                           /* 1: SOF2 (progressive DCT, Huffman): scan_offset = the first SOS marker; decoded through
                                                   gdt_jpeg_progressive_coefficients + gdt_jpeg_decode_coef_u8_batch (below) */
-    int comp_id[3];                            /* progressive files: the frame's component identifiers (their scans name components by id) */
+    int comp_id[4];                            /* progressive files: the frame's component identifiers (their scans name components by id) */
+    int adobe_transform;                       /* four-component files: 2 = YCCK (Adobe APP14 transform 2), 0 = CMYK (transform 0, or no Adobe marker); the decoded
+                                                  CMYK samples are taken as inverted ("Adobe convention", as Pillow's JPEG plugin does for every CMYK file) and
+                                                  converted to RGB with Pillow's convert('RGB') arithmetic: the reference's pil_loader, datahelpers.py:39-47 */
 } gdt_jpeg_info;
 int gdt_jpeg_parse(const unsigned char* file, size_t nbytes, gdt_jpeg_info* info);
 int gdt_jpeg_extract_scan(const unsigned char* file, size_t nbytes, const gdt_jpeg_info* info, unsigned char* dst, unsigned int* seg_off);
@@ -284,7 +287,7 @@ typedef struct gdt_jpeg_item {
     const gdt_jpeg_info* info;     /* host */
     const unsigned char* scan;     /* device: the bytes gdt_jpeg_extract_scan produced (scan_capacity of them) */
     const unsigned int* seg_off;   /* host: info->nsegments + 1 offsets into scan */
-    unsigned char* dst_hwc;        /* device: [height][width][3] uint8 RGB (grayscale replicated, as convert('RGB') does) */
+    unsigned char* dst_hwc;        /* device: [height][width][3] uint8 RGB (grayscale replicated, CMYK converted, as convert('RGB') does) */
 } gdt_jpeg_item;
 int gdt_jpeg_decode_workspace_bytes(const gdt_jpeg_item* items, int n, size_t* bytes);
 int gdt_jpeg_decode_u8_batch(const gdt_jpeg_item* items, int n, int mode, void* workspace, size_t workspace_bytes, void* stream);

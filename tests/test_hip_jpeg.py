@@ -2,6 +2,7 @@
 Image.open(f).convert('RGB') (mdir/external/cirtorch/datasets/datahelpers.py:39-47): byte-exact, every sampling mode Pillow writes,
 odd sizes, custom Huffman tables, restart intervals, both entropy decoders (parallel pieces / one thread per interval)."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -103,10 +104,10 @@ def test_batch_of_mixed_files_equals_one_by_one():
 
 
 def test_unsupported_files_raise_and_host_loader_is_explicit():
-    cmyk = _encode(_picture(32, 32, 2).convert("CMYK"), quality=80)
+    cmyk = _encode(_picture(32, 32, 2), quality=80, keep_rgb=True)        # (an RGB-coded file: no colour transform -- one of the kinds the device decoder leaves to the host)
     png = io.BytesIO()
     _picture(20, 20, 3).save(png, "PNG")
-    for blob, word in ((cmyk, "three-component"), (png.getvalue(), "SOI")):
+    for blob, word in ((cmyk, "RGB-coded"), (png.getvalue(), "SOI")):
         with pytest.raises(ValueError, match=word):
             jpeg.parse(blob)
     good = _encode(_picture(48, 40, 4), quality=90)
@@ -172,6 +173,32 @@ def test_golden_files():
         got = jpeg.decode_many(blobs, "cuda:0", sequential=sequential)
         for n, t in zip(g["names"], got):
             assert np.array_equal(t.cpu().numpy(), g["rgb_" + str(n)]), (str(n), sequential)
+
+
+def test_four_component_files_match_pillow():
+    """CMYK files as Pillow writes them (Adobe marker, transform 0; with `subsampling` only the first component keeps full resolution), the same bitstreams declared
+    YCCK (transform 2: what Photoshop writes) or stripped of the Adobe marker, baseline and progressive, with restart intervals, in one mixed call with YCbCr and
+    gray files: byte-identical to Image.open(f).convert('RGB') (pil_loader, datahelpers.py:39-47)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_jpeg_golden import as_ycck, without_adobe
+    rng = np.random.RandomState(11)
+    blobs = []
+    for i, (w, h) in enumerate([(64, 48), (97, 61), (33, 17), (120, 90), (8, 8), (1, 1)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        arr = np.stack([(xx * 3 + yy * (c + 1) * 2 + 40 * c) % 256 for c in range(4)], -1).astype(np.float64) + rng.normal(0, 12, (h, w, 4))
+        img = Image.fromarray(np.clip(arr, 0, 255).astype(np.uint8), "CMYK")
+        for opts in (dict(quality=90), dict(quality=75, subsampling=2), dict(quality=85, subsampling=1, restart_marker_blocks=3), dict(quality=80, progressive=True),
+                     dict(quality=70, subsampling=2, progressive=True)):
+            blob = _encode(img, **opts)
+            blobs += [blob, as_ycck(blob)]
+        blobs.append(without_adobe(_encode(img, quality=88)))
+    blobs.append(_encode(_picture(50, 40, 9), quality=85, subsampling=2))
+    blobs.append(_encode(_picture(40, 30, 10).convert("L"), quality=80))
+    for sequential in (False, True):
+        got = jpeg.decode_many(blobs, "cuda:0", sequential=sequential)
+        for k, (t, blob) in enumerate(zip(got, blobs)):
+            assert np.array_equal(t.cpu().numpy(), _reference(blob)), (k, sequential)
 
 
 def test_corrupted_entropy_data_decodes_to_something_without_harm():

@@ -70,8 +70,16 @@ def test_unsupported_kinds_are_refused_with_the_reason():
     assert prog.info.progressive == 1 and prog.size == (40, 40)
     buf = io.BytesIO()
     Image.fromarray(arr).convert("CMYK").save(buf, "JPEG")
-    with pytest.raises(ValueError, match="three-component"):
-        jpeg.parse(buf.getvalue())
+    cmyk = jpeg.parse(buf.getvalue())                                     # four components (Adobe transform 0): decoded and converted like Pillow's convert('RGB')
+    assert cmyk.info.ncomp == 4 and cmyk.info.adobe_transform == 0 and cmyk.info.blocks_per_mcu == 4 and cmyk.mode == "RGB"
+    buf = io.BytesIO()
+    Image.fromarray(arr).convert("CMYK").save(buf, "JPEG", subsampling=2)
+    assert jpeg.parse(buf.getvalue()).info.blocks_per_mcu == 7            # first component 2 x 2, the others 1 x 1
+    two = bytearray(_encode(arr, quality=80))                             # a frame that claims two components
+    sof = two.index(b"\xff\xc0")
+    two[sof + 9] = 2
+    with pytest.raises(ValueError):
+        jpeg.parse(bytes(two))
     with pytest.raises(ValueError, match="SOI"):
         jpeg.parse(b"\x89PNG\r\n\x1a\n" + bytes(64))
     good = _encode(arr, quality=80)
