@@ -489,6 +489,9 @@ def main():
                                         "three-pass f16x3 split"},
                 "ms_per_step_hip_events": None if gen_event_ms is None else round(gen_event_ms, 3),
                 "whole_net_tflops_per_gpu": round(gen_tflops, 1),
+                "timed_region_s": round(gen_ms * a.steps / 1e3, 3),
+                "steady_state_note": "a timed region under ~1 s (the driver's --steps 20: 0.2 s) runs at clocks the part does not hold; the default 100-step run of "
+                                     "the same build measures 6.15-6.26 k images/s (profiles/r04_bench_line.json)",
                 "parity": "north_star gates met by this mode: generator max|d|/max|ref| <= 1e-3 at every tap and pre-tanh -- measured against the "
                           "CPU oracle: 4.6e-4 ... 4.9e-4 pre-tanh at batch 64 (taps 7e-5 ... 1.5e-4), image max|d| 6.6e-4 / 7.2e-4 absolute at "
                           "max|pre-tanh| 1.5 (IN / BN weights), hub seed-0 fixture (saturated, |pre-tanh| 35) mean 2.97e-4, p99.9 7.5e-3, max 9.6e-3; "
