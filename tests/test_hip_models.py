@@ -319,3 +319,28 @@ def test_forward_many_equals_level_by_level_forward(cuda_device):
     assert all(w is None for w in net._side["ws"])
     for w, g in zip(want, got2):
         assert all(torch.equal(a, b) for a, b in zip(w, g))
+
+
+def test_hipgraph_replay_equals_eager_launches(cuda_device):
+    """opt-in hipGraph replay of whole forwards (GANDTR_HIP_GRAPHS=1 / HipNet.use_graphs): from the second call of a geometry on the forward is captured once and
+    replayed -- same kernels, same results bit for bit, for the generator (f16c) and the embedder; another geometry falls back to eager launches"""
+    from gandtr_amd import engine
+    gen = engine.build_generator(synth.generator_state(0, "instance"), cuda_device, pre_tanh=True)
+    emb = engine.build_embedder(synth.resnet101_state(0), cuda_device)
+    for net, shape in ((gen, (4, 3, 128, 128)), (emb, (2, 3, 256, 320))):
+        x = synth.synth_input(77, shape, 1.0).to(cuda_device)
+        eager = net.forward(x)[net.out_slot].clone()
+        net.use_graphs = True
+        outs = [net.forward(x)[net.out_slot].clone() for _ in range(3)]         # eager (first sighting was above), capture + replay, replay
+        assert len(net._graphs) == 1
+        for o in outs:
+            assert torch.equal(o, eager)
+        x2 = synth.synth_input(78, shape, 1.0).to(cuda_device)
+        want = None
+        net.use_graphs = False
+        want = net.forward(x2)[net.out_slot].clone()
+        net.use_graphs = True
+        assert torch.equal(net.forward(x2)[net.out_slot], want)                    # replay with new input data
+        other = synth.synth_input(79, (1,) + shape[1:], 1.0).to(cuda_device)
+        assert net.forward(other)[net.out_slot].shape[0] == 1                      # new geometry: eager again
+        net.use_graphs = False
