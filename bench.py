@@ -173,7 +173,10 @@ def pmc_traffic(kernel, key):
     try:
         with open(os.path.join(ROOT, "profiles", key)) as f:
             doc = json.load(f)
-        return doc["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+        # (the profiler names conv3x3_expand_rb_kernel by its patch-height template argument, bench.py by the expand conv's channel count)
+        alias = {"conv3x3_expand_rb_kernel<1024>": "conv3x3_expand_rb_kernel<8>"}
+        ks = doc["kernels"]
+        return (ks[kernel] if kernel in ks else ks[alias[kernel]])["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -448,7 +451,7 @@ def main():
             return d
         dt2 = timed(step, a.steps, a.warmup, dev, distributed)
         r_dps = n_total * a.steps / dt2
-        roof2 = conv_roofline(emb, xe) if rank == 0 else None
+        roof2 = conv_roofline(emb, xe, traffic_key="r04_pmc_traffic_r101.json" if a.r101_batch == 32 else None) if rank == 0 else None
         if roof2 is not None and roof2.get("kernel", "").startswith("conv3x3_expand"):
             # the dominant launch is half MFMA-bound (3x3), half HBM-bound (expand + residual + store): both views of the same launches
             roof2["hbm_view"] = {"bound": "hbm", "achieved": round(roof2["algorithmic_bytes_per_launch"] / (roof2["avg_launch_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0,
