@@ -152,7 +152,7 @@ def test_projection_shortcut_folded_into_the_expand_conv(cuda_device, stride, ci
     assert torch.equal(outs[taps[2]], net.forward(xi.to(cuda_device))[taps[2]])
 
 
-@pytest.mark.parametrize("n,h,w", [(16, 64, 64), (16, 62, 64), (18, 64, 60)], ids=["whole-patches", "ragged-rows", "ragged-columns"])
+@pytest.mark.parametrize("n,h,w", [(16, 64, 64), (16, 62, 64), (18, 64, 60), (29, 46, 46)], ids=["whole-patches", "ragged-rows", "ragged-columns", "ragged-both-724px-level"])
 def test_fused_3x3_expand_layer3(cuda_device, n, h, w, monkeypatch):
     """ResNet-101 layer3 geometry (C 1024, MID 256: the block does not fit conv_bneck's LDS plan): the 3x3 conv and the expand conv + residual run as ONE launch
     (conv3x3_expand_rb.hip, variant 939000 + C / 8; the 256-channel tensor between them stays in LDS) -- against fp64 on the same fp16-rounded input with r and t
