@@ -257,6 +257,11 @@ def main():
             r, ms = rate(lambda: net(x), 8, steps=4, warmup=1)
             gf = 574.8 if scales is True else 1151.9
             out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1)}
+            if scales is True:                      # the same network on a batch of 32 (what a rank holds when the global batch is 256): the large-geometry kernels apply
+                x32 = synth.synth_input(5, (32, 3, 1024, 1024)).to(dev)
+                r32, ms32 = rate(lambda: net(x32), 32, steps=4, warmup=1)
+                out["c3_gem_resnet101_ms_%s_32x1024" % tag] = {"descriptors_per_s": r32, "ms_per_batch": ms32, "tflops": round(r32 * gf / 1e3, 1)}
+                del x32
             del net
         del x
         torch.cuda.empty_cache()
