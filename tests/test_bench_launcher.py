@@ -72,6 +72,15 @@ def test_self_launch_four_ranks_dry_run():
     assert doc["n_gpus"] == 4 and doc["rccl_ranks"] == 4 and doc["dry_run"] is True
 
 
+def test_self_launch_eight_ranks_dry_run():
+    """the driver's `--gpus 8` case (one rank per GPU of a node), rehearsed on gloo"""
+    rc, lines, err = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 8 and doc["rccl_ranks"] == 8 and doc["dry_run"] is True
+
+
 def _configs(args):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
