@@ -59,6 +59,9 @@
 #ifndef GDT_C_DEPTH_SHIFT
 #define GDT_C_DEPTH_SHIFT 2     // ... shift forms (stride-2, transposed): little matrix work per halo byte, the rounds in flight set the HBM rate
 #endif
+#ifndef GDT_C_DEPTH_S2_W8
+#define GDT_C_DEPTH_S2_W8 2     // ... the eight-wave 128-column stride-2 form (registers to spare)
+#endif
 #ifndef GDT_C_DEPTH_SHIFT_RES
 #define GDT_C_DEPTH_SHIFT_RES 2
 #endif
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_c_kernel(const Co
     // staging schedule: a chunk has NTAP * 4 k-substep slots; loader round r is issued at slot r * SPR and written to LDS at slot
     // (r + 1) * SPR (one piece in flight per thread, SPR substeps of MFMAs to cover its latency)
     // (the shift forms have 16 substeps for 10 rounds, one substep apart: they keep DEPTH = 2 rounds in flight instead)
-    constexpr int SLOTS = NTAP * 4, DEPTH = SHIFT ? (RES ? GDT_C_DEPTH_SHIFT_RES : GDT_C_DEPTH_SHIFT) : ((MODE & 6) ? GDT_C_DEPTH_RES : GDT_C_DEPTH), SPR = SLOTS / (NR + DEPTH);
+    constexpr int SLOTS = NTAP * 4, DEPTH = (FORM == 2 && WGM * WGN == 8) ? GDT_C_DEPTH_S2_W8 : SHIFT ? (RES ? GDT_C_DEPTH_SHIFT_RES : GDT_C_DEPTH_SHIFT) : ((MODE & 6) ? GDT_C_DEPTH_RES : GDT_C_DEPTH), SPR = SLOTS / (NR + DEPTH);
     static_assert(SPR >= 1 && (NR + DEPTH - 1) * SPR < SLOTS && HROWS_PAD <= HALO_ROWS_PAD, "halo rounds are spread over the substeps of the previous chunk");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -845,12 +848,16 @@ static int c_dbg() { static const int v = [] { const char* e = getenv("GDT_C_DBG
 // weight bytes per MFMA as 1 x 4 (a weight fragment still feeds 8 MFMAs), twice its LDS fragment bytes (an activation fragment feeds one
 // MFMA); what it buys is a second wave per SIMD: while one waits -- for a weight fragment behind older halo loads (vmcnt retires in
 // order), for an LDS fragment, at the address unit -- the other issues.
+// W8 with BN_ = 128 (the 64 -> 128 stride-2 layer): eight waves as 2 x 4, a wave = 128 pixels x 32 channels.  That layer has little matrix work per halo byte and its
+// four-wave form spends a tile adding up what ONE wave per SIMD must issue in order: staging arithmetic, loads, fragment reads, MFMAs.
 template <int MODE, int FORM = 0, bool TALL = false, int BN_ = 256, bool W8 = false>
 int launch_c(const ConvLaunch& d, hipStream_t stream) {
-    constexpr int BN = BN_, WGM = TALL ? 1 : 2, WGN = TALL ? (W8 ? 8 : 4) : 2;
+    constexpr int BN = BN_, WGM = TALL ? 1 : 2, WGN = TALL ? (W8 ? 8 : 4) : (W8 ? 4 : 2);
     constexpr size_t LDS_BYTES = lds_bytes(WGM * WGN);
     static_assert(BN == 256 || (BN == 128 && !TALL), "tile width");
-    static_assert(!W8 || (TALL && FORM == 0), "the eight-wave layout exists for the 3x3 form");
+    // (the transposed form's compile-time skipping of zero weight blocks assumes that a wave's column blocks ARE the four sub-pixel phases, i.e. four blocks per wave:
+    //  with 2 x 4 waves the phases of a wave depend on its column -- not instantiated; the 256-column stride-2 form spills at 256 registers: 0.35 -> 0.61 ms)
+    static_assert(!W8 || (TALL && FORM == 0) || (!TALL && MODE == 1 && FORM == 2 && BN == 128), "the eight-wave layouts: 1 x 8 for the 3x3 form; 2 x 4 for the 128-column stride-2 form");
     const int gh = FORM == 2 ? d.OH : d.H, gw = FORM == 2 ? d.OW : d.W;
     const int tiles = d.N * ((gw + 15) / 16) * ((gh + PH - 1) / PH), ntn = d.CoutPad / BN;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -1022,6 +1029,8 @@ int gdt_launch_conv_halo_c_s2(const ConvLaunch& d_in, hipStream_t stream) {
     ConvLaunch d = d_in;
     d.dbg = c_dbg();
     if (d.CoutPad % 256 != 0) {
+        static const int w8s2 = [] { const char* e = getenv("GDT_C_S2_WAVES"); return e ? atoi(e) == 8 : true; }();      // two waves per SIMD (2 x 4): 0.55 -> 0.51 ms; GDT_C_S2_WAVES=4: back to four
+        if (w8s2 && d.in_norm && !d.in_out) return launch_c<1, 2, false, 128, true>(d, stream);
         if (!d.in_norm) return launch_c<0, 2, false, 128>(d, stream);
         return d.in_out ? launch_c<5, 2, false, 128>(d, stream) : launch_c<1, 2, false, 128>(d, stream);
     }
