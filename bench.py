@@ -124,8 +124,6 @@ def timed(fn, steps, warmup, dev, distributed):
 def kernel_name(variant):
     if variant >= 990000:
         return "conv3x3_halo_c_kernel<256>[stride-2]"
-    if variant >= 981000:
-        return "conv_ct_c16_kernel"                                    # the transposed form on the 16 x 16 MFMA shapes
     if variant >= 980000:
         return "conv3x3_halo_c_kernel<256>[transposed]"
     if variant >= 971000:

@@ -259,17 +259,20 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
 
 template <bool RES, int DEPTH, int TM, bool CAT = false>
 int launch_1x1(const ConvLaunch& d, hipStream_t stream) {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0, per_cu = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        GDT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, NT, LDS_BYTES));
-        static const int cap = [] { const char* e = getenv("GDT_CONV_1X1_WPC"); return e ? atoi(e) : 3; }();
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > cap) per_cu = cap;
-        slots = cus / 8 * 8 * per_cu;                 // a multiple of 8: a workgroup's tiles stay on its XCD
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int slots = 0;
+    {
+        const int rc = gdt_per_device(per_dev, slots, [](int, int cus, int& v) {
+            int per_cu = 0;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            GDT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, NT, LDS_BYTES));
+            static const int cap = [] { const char* e = getenv("GDT_CONV_1X1_WPC"); return e ? atoi(e) : 3; }();
+            if (per_cu < 1) per_cu = 1;
+            if (per_cu > cap) per_cu = cap;
+            v = cus / 8 * 8 * per_cu;                 // a multiple of 8: a workgroup's tiles stay on its XCD
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles((d.M + BM - 1) / BM, d.CoutPad / (TM == 4 ? 256 : 128));
     const int grid = vblocks < slots ? vblocks : slots;

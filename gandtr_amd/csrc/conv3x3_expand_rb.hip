@@ -396,15 +396,22 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
 
 // Eligible: 3x3 / stride 1 / zero pad 1, 256 -> 256 channels with fragment-ordered weights and a bias (BatchNorm folded), ReLU; expand 1x1 to a multiple of 256
 // channels with bias, residual and ReLU; enough patches for one per CU; at most 15 % of the patch area hanging over the image.
+static int xexp_patch_height() {
+    static const int ph = [] { const char* e = getenv("GDT_XEXP_PH"); return e ? atoi(e) : 8; }();       // 16: one 512-thread workgroup per CU on 16 x 16 patches
+    return ph == 16 ? 16 : 8;
+}
+
 bool gdt_conv3x3_expand_eligible(const ConvLaunch& d) {
     if (!d.w_frag || !d.x_w_frag || !d.bias || !d.x_bias || !d.res || !d.out || d.out_f32) return false;
     if (d.Cin != 256 || d.Cout != 256 || d.CoutPad != 256 || d.x_cout < 256 || d.x_cout % 256 != 0) return false;
     if (d.ntaps != 9 || d.sy != 1 || d.sx != 1 || d.pad_reflect || d.in_norm || d.in_res || d.in_out || d.stats || d.pool2 || d.phase_cout || !d.relu) return false;
     if ((long)d.N * d.H * d.W * d.x_cout >= (1L << 32)) return false;                                  // 32-bit element offsets
-    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16);
-    const double useful = (double)d.H * d.W / ((double)((d.H + 15) / 16 * 16) * ((d.W + 15) / 16 * 16));
+    // (both figures for the patch height that WILL be launched: PH x 16 patches, 16 / PH workgroups per CU -- GDT_XEXP_MIN_TILES counts 16 x 16 patches' worth of work)
+    const int ph = xexp_patch_height();
+    const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + ph - 1) / ph);
+    const double useful = (double)d.H * d.W / ((double)((d.H + ph - 1) / ph * ph) * ((d.W + 15) / 16 * 16));
     static const int min_tiles = [] { const char* e = getenv("GDT_XEXP_MIN_TILES"); return e ? atoi(e) : 256; }();
-    return tiles >= min_tiles && useful >= 0.85;
+    return tiles * ph >= (long)min_tiles * 16 && useful >= 0.85;
 }
 
 template <int PH>
@@ -412,13 +419,15 @@ static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
     using G = Geo<PH>;
     ConvLaunch d = d_in;
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_expand_rb_kernel<PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_expand_rb_kernel<PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles(tiles, 1), slots = cus * (PH == 16 ? 1 : 2);
     int grid = vblocks < slots ? vblocks : slots;
@@ -452,6 +461,5 @@ static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
 }
 
 int gdt_launch_conv3x3_expand(const ConvLaunch& d, hipStream_t stream) {
-    static const int ph = [] { const char* e = getenv("GDT_XEXP_PH"); return e ? atoi(e) : 8; }();       // 16: one 512-thread workgroup per CU on 16 x 16 patches
-    return ph == 16 ? launch_xexp<16>(d, stream) : launch_xexp<8>(d, stream);
+    return xexp_patch_height() == 16 ? launch_xexp<16>(d, stream) : launch_xexp<8>(d, stream);
 }

@@ -284,11 +284,16 @@ int launch_halo(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + PH - 1) / PH), ntn = d.CoutPad / BN;
     constexpr size_t lds = halo_lds_bytes<PH, BN, WGM, WGN>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<PH, BN, WGM, WGN>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static GdtPerDevice per_dev;          // one attribute call per template instantiation AND device (gdt_common.h)
+    int attr_set = 0;
+    {
+        const int rc = gdt_per_device(per_dev, attr_set, [](int, int, int& v) {
+            v = 1;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_kernel<PH, BN, WGM, WGN>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<PH, BN, WGM, WGN>), dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(WGM * WGN * 64), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());

@@ -861,13 +861,15 @@ int launch_c(const ConvLaunch& d, hipStream_t stream) {
     const int gh = FORM == 2 ? d.OH : d.H, gw = FORM == 2 ? d.OW : d.W;
     const int tiles = d.N * ((gw + 15) / 16) * ((gh + PH - 1) / PH), ntn = d.CoutPad / BN;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c_kernel<BN, WGM, WGN, MODE, FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     const int grid = vblocks < cus ? vblocks : cus;

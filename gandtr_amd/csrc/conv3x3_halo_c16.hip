@@ -622,13 +622,15 @@ template <int MODE>
 int launch_c16(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * (d.W >> 4) * (d.H >> 4), ntn = d.CoutPad >> 8;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_c16_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     const int grid = vblocks < cus ? vblocks : cus;

@@ -469,13 +469,15 @@ int launch_rb(const ConvLaunch& d, hipStream_t stream) {
     constexpr size_t lds = rb_lds_bytes<BN, PHT, SINGLE>();
     static_assert(!SINGLE || 2 * lds <= 160 * 1024, "two workgroups per CU");
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_kernel<BN, WGM, WGN, MODE, CT, PHT, SINGLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles(tiles, ntn);
     static const int persist = [] { const char* e = getenv("GDT_RB_PERSIST"); return e ? atoi(e) : 1; }();

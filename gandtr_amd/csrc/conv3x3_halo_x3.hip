@@ -243,10 +243,15 @@ int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) {
     const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16), ntn = d.CoutPad / BN;
     constexpr size_t lds = 2 * (size_t)STAGE_A + 2 * (size_t)STAGE_B;
     static_assert(lds <= 160 * 1024 && (size_t)4 * BN * 8 <= lds, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static GdtPerDevice per_dev;          // one attribute call per template instantiation AND device (gdt_common.h)
+    int attr_set = 0;
+    {
+        const int rc = gdt_per_device(per_dev, attr_set, [](int, int, int& v) {
+            v = 1;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     hipLaunchKernelGGL(conv3x3_halo_x3_kernel, dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(NT), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());

@@ -460,13 +460,15 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
 template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
 int launch(const BneckLaunch& d, hipStream_t stream) {
     using G = Geo<C, MID, PH, CIN, DS>;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH, CIN, DS, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_kernel<C, MID, PH, CIN, DS, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
     const int grid = min(cus, (ntiles + 7) / 8 * 8);

@@ -362,16 +362,18 @@ bool gdt_conv_head7_eligible(const ConvLaunch& d) {
 }
 
 int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
-    static int cus = 0;
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
     constexpr int lds = HBYTES;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int ntiles = d.N * ((d.W + PW - 1) / PW) * ((d.H + PH - 1) / PH);
     static const int wgs = [] { const char* e = getenv("GDT_HEAD7_WGS"); return e ? atoi(e) : 2; }();

@@ -278,11 +278,16 @@ int launch_cfg(const ConvLaunch& d, hipStream_t stream) {
     constexpr size_t lds = lds_bytes<BM, BN, WGM, WGN>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
     if (lds > 64 * 1024) {
-        static bool attr_set = false;     // one attribute call per template instantiation
-        if (!attr_set) {
-            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WGM, WGN, NORM>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+        static GdtPerDevice per_dev;          // one attribute call per template instantiation AND device (gdt_common.h)
+        int attr_set = 0;
+        {
+            const int rc = gdt_per_device(per_dev, attr_set, [](int, int, int& v) {
+                v = 1;
+                GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WGM, WGN, NORM>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                return GDT_OK;
+            });
+            if (rc != GDT_OK) return rc;
         }
     }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, NORM>), dim3(gdt_grid_for_tiles(ntm, ntn)), dim3(WGM * WGN * 64), lds, stream, d);

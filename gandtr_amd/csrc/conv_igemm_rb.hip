@@ -378,13 +378,15 @@ template <int BN, int WGM, int WGN, bool NORM, bool CTF = false>
 int launch_irb(const ConvLaunch& d, hipStream_t stream) {
     constexpr size_t lds = irb_lds_bytes<BN, WGM>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_rb_kernel<BN, WGM, WGN, NORM, CTF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_rb_kernel<BN, WGM, WGN, NORM, CTF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int vblocks = gdt_grid_for_tiles((d.M + BM - 1) / BM, d.CoutPad / BN);
     const int grid = vblocks < cus ? vblocks : cus;

@@ -268,13 +268,15 @@ template <int KS, int S, bool AUG = false>
 int launch_stem(const ConvLaunch& d, hipStream_t stream) {
     using C = StemCfg<KS, S>;
     static_assert(2 * C::LDS <= 160 * 1024, "two workgroups per CU");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_kernel<KS, S, AUG>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_kernel<KS, S, AUG>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + C::TH - 1) / C::TH);
     const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
@@ -698,13 +700,15 @@ template <int KS, int S>
 static int launch_stem_pair(const ConvLaunch& d, const StemPairArgs& a, hipStream_t stream) {
     using C = PairCfg<KS, S>;
     static_assert(2 * C::LDS <= 160 * 1024, "two workgroups per CU");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_kernel<KS, S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     const int ntiles = d.N * ((d.OW + TW - 1) / TW) * ((d.OH + C::TH - 1) / C::TH);
     const int grid = min(2 * cus, (ntiles + 7) / 8 * 8);
@@ -727,13 +731,15 @@ int gdt_launch_conv_stem_pair_pool(const ConvLaunch& d, const float* x, int C, c
     GDT_REQUIRE(x != nullptr && C >= 1 && C <= 3, "stem: 1..3 image channels");
     GDT_REQUIRE(PH == (d.OH - 1) / 2 + 1 && PW == (d.OW - 1) / 2 + 1, "stem: pooled size");
     static_assert(2 * SQ_LDS <= 160 * 1024, "two workgroups per CU");
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        GDT_CHECK_HIP(hipGetDevice(&dev));
-        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        cus = cus / 8 * 8;
-        GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS));
+    static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_stem_pair_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SQ_LDS));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
     }
     StemPairArgs a;
     a.x = x; a.C = C;

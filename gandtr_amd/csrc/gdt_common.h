@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 
 typedef _Float16 f16;
@@ -38,6 +39,34 @@ void gdt_set_error(const std::string& msg);
             return GDT_ERR_INVALID;                                                             \
         }                                                                                       \
     } while (0)
+
+// ---- one-time set-up of a kernel PER DEVICE ----
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and a process may build nets on several GPUs and launch from
+// several threads (the JPEG staging explicitly supports that): the launchers keep their "done" state per device id behind a mutex.  `setup(dev, cus,
+// value)` runs once per device with the device's CU count and leaves the launcher's cached figure in `value` (non-zero).
+struct GdtPerDevice {
+    std::mutex mu;
+    int value[64] = {};
+};
+template <typename Setup>
+inline int gdt_per_device(GdtPerDevice& st, int& out, Setup&& setup) {
+    int dev = 0;
+    GDT_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        gdt_set_error("device id out of range");
+        return GDT_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (!st.value[dev]) {
+        int cus = 0, v = 0;
+        GDT_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int rc = setup(dev, cus, v);
+        if (rc != GDT_OK) return rc;
+        st.value[dev] = v ? v : 1;
+    }
+    out = st.value[dev];
+    return GDT_OK;
+}
 
 // ---- implicit-GEMM convolution launch descriptor ----
 // Activations are NHWC fp16; weights are packed [CoutPad][Kpad] fp16 with k = tap * Cin + c.
@@ -166,8 +195,6 @@ bool gdt_conv_halo_c16_eligible(const ConvLaunch& d);       // conv3x3_halo_c16.
 int gdt_launch_conv_halo_c16(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_ct_eligible(const ConvLaunch& d);      // ... transposed form (variant 980256)
 int gdt_launch_conv_halo_c_ct(const ConvLaunch& d, hipStream_t stream);
-bool gdt_conv_ct_c16_eligible(const ConvLaunch& d);         // conv_ct_c16.hip: the transposed form on the 16 x 16 MFMA shapes (variant 981256)
-int gdt_launch_conv_ct_c16(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_s2_eligible(const ConvLaunch& d);      // ... stride-2 form over the virtual space-to-depth input (variant 990256)
 int gdt_launch_conv_halo_c_s2(const ConvLaunch& d, hipStream_t stream);
 bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W);   // conv_bneck.hip: Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut) as one launch (variant 935000 + C)

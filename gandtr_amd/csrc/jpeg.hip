@@ -70,6 +70,19 @@ struct DSeg {
     unsigned first_block, nblocks;                 // scan-order block numbers within the image
     unsigned first_sub, nsub, sub_bits;
 };
+// A DHT segment's 16 code-length counts must describe a prefix code (the Kraft check the library makes before it builds its look-up tables):
+// with codes assigned in order, the codes of length l must fit l bits and none may be all ones (T.81 C.2; the library refuses such a file, and so
+// does the reference's loader).  An over-subscribed table (e.g. three codes of length 1) would index past every table built from it.
+inline bool huff_lengths_valid(const unsigned char* bits /* [17], [0] unused */) {
+    long long code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        code += bits[l];
+        if (code >= (1LL << l)) return false;
+        code <<= 1;
+    }
+    return true;
+}
+
 struct DTab {
     unsigned short look[4][512];                   // 9-bit prefix -> (length << 8 | symbol), 0 = longer code
     int maxcode[4][18];                            // largest code of each length (-1: none)
@@ -446,7 +459,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
     memset(info, 0, sizeof(*info));
     if (n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail("not a JPEG file (no SOI marker)");
     Reader r{f, n, 2};
-    bool have_frame = false, have_q[4] = {false, false, false, false}, have_h[4] = {false, false, false, false}, jfif = false, adobe = false;
+    bool have_frame = false, have_q[4] = {false, false, false, false}, have_h[4] = {false, false, false, false}, bad_h[4] = {false, false, false, false}, jfif = false, adobe = false;
     int adobe_transform = -1, comp_id[4] = {0, 0, 0, 0};
     for (;;) {
         if (!r.has(2)) return fail("truncated before the scan");
@@ -487,9 +500,9 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
                 if (tc > 1 || th > 3) return fail("bad Huffman table number");
                 if (th > 1) {                  // tables 2 / 3: progressive files only (their coefficient decoder reads the tables itself)
                     if (!info->progressive && have_frame) return fail("Huffman table numbers above 1 (not baseline)");
-                    int total = 0;
-                    for (int l = 1; l <= 16; ++l) total += r.u8();
-                    if (total > 256 || end - r.pos < (size_t)total) return fail("bad Huffman table");
+                    int total = 0; unsigned char hb[17] = {0};
+                    for (int l = 1; l <= 16; ++l) { hb[l] = (unsigned char)r.u8(); total += hb[l]; }
+                    if (total > 256 || end - r.pos < (size_t)total) return fail("bad Huffman table");      // (its lengths are checked by the coefficient decoder, at use)
                     r.pos += total;
                     continue;
                 }
@@ -498,6 +511,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
                 info->huff_bits[idx][0] = 0;
                 for (int l = 1; l <= 16; ++l) { info->huff_bits[idx][l] = (unsigned char)r.u8(); total += info->huff_bits[idx][l]; }
                 if (total > 256 || end - r.pos < (size_t)total) return fail("bad Huffman table");
+                bad_h[idx] = !huff_lengths_valid(info->huff_bits[idx]);
                 memset(info->huff_vals[idx], 0, 256);
                 for (int i = 0; i < total; ++i) info->huff_vals[idx][i] = (unsigned char)r.u8();
                 have_h[idx] = true;
@@ -534,6 +548,7 @@ int parse_impl(const unsigned char* f, size_t n, gdt_jpeg_info* info) {
                 info->td[c] = tt >> 4; info->ta[c] = tt & 15;
                 if (info->td[c] > 1 || info->ta[c] > 1) return fail("Huffman table numbers above 1 (not baseline)");
                 if (!have_h[info->td[c]] || !have_h[2 + info->ta[c]]) return fail("scan refers to a Huffman table that was not defined");
+                if (bad_h[info->td[c]] || bad_h[2 + info->ta[c]]) return fail("bad Huffman table (its code lengths are not a prefix code)");
                 if (!have_q[info->tq[c]]) return fail("frame refers to a quantisation table that was not defined");
             }
             const int ss = r.u8(), se = r.u8(), ahal = r.u8();
@@ -748,8 +763,11 @@ struct HuffHost {
     int maxcode[18], valptr[17], mincode[17];
     unsigned char vals[256];
     unsigned short look[512];                     // 9-bit prefix -> (length << 8 | symbol), 0 = longer code
-    bool defined = false;
+    bool defined = false, bad = false;            // bad: defined by a DHT whose lengths are no prefix code -- an error once a scan uses it (as in the library)
     void build(const unsigned char* bits /* [17] */, const unsigned char* v) {
+        defined = true;
+        bad = !huff_lengths_valid(bits);
+        if (bad) return;                              // (with valid lengths every code fits its length: code << (9 - l) stays below 512)
         memcpy(vals, v, 256);
         memset(look, 0, sizeof(look));
         int code = 0, k = 0;
@@ -761,7 +779,6 @@ struct HuffHost {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
-        defined = true;
     }
 };
 
@@ -916,6 +933,7 @@ int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info
         for (int i = 0; i < ns; ++i) {
             if (Ss == 0 && Ah == 0 && !dc[td[i]].defined) return fail("scan refers to a Huffman table that was not defined");
             if (Ss > 0 && !ac[ta[i]].defined) return fail("scan refers to a Huffman table that was not defined");
+            if ((Ss == 0 && Ah == 0 && dc[td[i]].bad) || (Ss > 0 && ac[ta[i]].bad)) return fail("bad Huffman table (its code lengths are not a prefix code)");
         }
         BitReader br{f, n, end};
         ++scans;
@@ -930,7 +948,7 @@ int progressive_impl(const unsigned char* f, size_t n, const gdt_jpeg_info& info
         for (long long u = 0; u < units; ++u) {
             if (until_restart == 0) {
                 br.restart();
-                pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+                pred[0] = pred[1] = pred[2] = pred[3] = 0; eobrun = 0;
                 until_restart = restart_interval;
             }
             if (until_restart > 0) --until_restart;

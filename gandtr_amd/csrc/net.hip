@@ -755,7 +755,7 @@ void pack_mx16(const std::vector<float>& wf, int cout_pad, int Kpad, std::vector
                 }
 }
 
-// the 15 KB records of conv3x3_halo_c16.hip / conv_ct_c16.hip from a [cols][Kpad] fp32 matrix (cols % 64 == 0, Kpad % 64 == 0)
+// the 15 KB records of conv3x3_halo_c16.hip from a [cols][Kpad] fp32 matrix (cols % 64 == 0, Kpad % 64 == 0)
 std::vector<unsigned char> pack_records16(const std::vector<float>& wf, int cols, int Kpad) {
     std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
     pack_mx16(wf, cols, Kpad, ma, mb, msc, wc);
@@ -1125,23 +1125,6 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 cf.wmx_b_off = net->blob_append(mb.data(), mb.size());
                 cf.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
                 cf.has_mx = true;
-                if (cd.cout % 16 == 0) {      // conv_ct_c16.hip: column = (cout / 16) * 64 + phase * 16 + cout % 16 -- a wave's four 16-column blocks are the four phases
-                    std::vector<float> w16((size_t)ncol * cf.Kpad, 0.f);
-                    for (int col = 0; col < ncol; ++col) {
-                        const int phase = (col >> 4) & 3, co = (col >> 6) * 16 + (col & 15);
-                        const int py = phase >> 1, px = phase & 1;
-                        for (int dy = 0; dy < 2; ++dy)
-                            for (int dx = 0; dx < 2; ++dx) {
-                                const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
-                                if (ky < 0 || kx < 0) continue;
-                                for (int c = 0; c < cd.cin; ++c)
-                                    w16[(size_t)col * cf.Kpad + (size_t)(dy * 2 + dx) * cin_pad + c] = weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co];
-                            }
-                    }
-                    const std::vector<unsigned char> rec = pack_records16(w16, ncol, cf.Kpad);
-                    cf.w16_off = net->blob_append(rec.data(), rec.size());
-                    cf.has_mx16 = true;
-                }
             }
             std::vector<f16> pf(net->precision ? 0 : pk.size());
             for (int cb = 0; cb < (net->precision ? 0 : ncol / 32); ++cb)
@@ -1405,11 +1388,14 @@ int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int*
     return GDT_OK;
 }
 
-int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, double* bytes) {
-    GDT_REQUIRE(net && bytes, "profile buffers");
+int gdt_net_num_ops(gdt_net* net) { return net ? (int)net->ops.size() : 0; }
+
+int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, int* n_ops, double* bytes) {
+    GDT_REQUIRE(net && bytes && n_ops, "profile buffers");
     GDT_REQUIRE(net->last_bytes.size() == net->ops.size(), "no profiled forward has run");
     GDT_REQUIRE(max_ops >= (int)net->ops.size(), "profile buffers too small");
     for (size_t i = 0; i < net->ops.size(); ++i) bytes[i] = net->last_bytes[i];
+    *n_ops = (int)net->ops.size();
     return GDT_OK;
 }
 
@@ -1546,6 +1532,10 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.in_relu = nj.relu;
                     if (nj.res >= 0) d.in_res = tptr(nj.res);
                     if (plan.steps[stp.norm_from].wb) d.in_out = tptr(nj.out);
+                    if (net->profiling) {       // bytes the folded form must move on top of the conv's own: the residual tensor read, the normalised tensor written back
+                        const double tb = (double)n * T[nj.in].H * T[nj.in].W * T[nj.in].C * (double)net->esize();
+                        net->last_bytes[stp.op] += tb * ((nj.res >= 0 ? 1.0 : 0.0) + (plan.steps[stp.norm_from].wb ? 1.0 : 0.0));
+                    }
                 }
                 d.res = o.res >= 0 ? tptr(o.res) : nullptr;
                 d.zeros = zeros;
@@ -1561,9 +1551,6 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.w_cfrag = net->dev_blob + o.ctf.wc_off; d.wmx_a = net->dev_blob + o.ctf.wmx_a_off; d.wmx_b = net->dev_blob + o.ctf.wmx_b_off; d.wmx_s = net->dev_blob + o.ctf.wmx_s_off;
                         d.c_lo_exp = 12; d.c_hi_exp = 0;
                         variant = 980256;
-                        if (o.ctf.has_mx16) d.w_c16 = net->dev_blob + o.ctf.w16_off;
-                        if (gdt_conv_ct_c16_eligible(d)) { variant = 981256; rc = gdt_launch_conv_ct_c16(d, st); }
-                        else
                         rc = gdt_launch_conv_halo_c_ct(d, st);
                     } else
                     rc = gdt_conv_halo_ct_eligible(d) ? gdt_launch_conv_halo_ct(d, st) : gdt_launch_conv_igemm_rb(d, st, &variant);

@@ -159,7 +159,7 @@ class HipNet:
 
     def profile(self):
         """per-op (kind, conv N-tile, ms, algorithmic flops) of the last profiled forward"""
-        cap = 1024
+        cap = max(1, int(self.lib.gdt_net_num_ops(self.handle)))
         n = ctypes.c_int()
         kinds, tiles = (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
         ms, fl = (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
@@ -168,10 +168,11 @@ class HipNet:
 
     def profile_bytes(self):
         """per-op algorithmic HBM bytes of the last profiled forward (same op order as profile())"""
-        cap = 1024
+        cap = max(1, int(self.lib.gdt_net_num_ops(self.handle)))
+        n = ctypes.c_int()
         by = (ctypes.c_double * cap)()
-        _hip.check(self.lib.gdt_net_profile_read_bytes(self.handle, cap, by))
-        return [by[i] for i in range(len(self.profile()))]
+        _hip.check(self.lib.gdt_net_profile_read_bytes(self.handle, cap, ctypes.byref(n), by))
+        return [by[i] for i in range(n.value)]
 
     def workspace_bytes(self, n, rh, rw):
         b = ctypes.c_size_t()

@@ -23,7 +23,7 @@ import torch
 from ..learning import load_network
 
 
-def extract_vectors(net, images, device=None, batched=None, max_batch=32, concurrent=8):
+def extract_vectors(net, images, device=None, batched=None, max_batch=32, concurrent=8, max_pixels=None):
     """D x N descriptor matrix of a list of image tensors (C x H x W or 1 x C x H x W); stays on ``device``.
 
     The reference runs one forward per image (batch-size-1 DataLoader, imageretrievalnet.py:319-333) because image sizes differ and its
@@ -33,7 +33,8 @@ def extract_vectors(net, images, device=None, batched=None, max_batch=32, concur
     The conv kernels are 3-4x more efficient at batch >= 8 than at batch 1.  ``batched=None``: on for a HIP device, off on the CPU
     (there the loop is the reference's own arithmetic, image by image); ``batched=False`` forces the reference's loop.  Groups of at most four images (sizes
     that occur rarely) go to the network together, up to ``concurrent`` images in flight (``SingleNetwork.forward_list``: one forward per group and pyramid
-    level, all issued before the first is joined; 48 images of 48 sizes through the multi-scale ResNet-101: 264 desc/s image by image, 388 with eight in flight)."""
+    level, all issued before the first is joined; 48 images of 48 sizes through the multi-scale ResNet-101: 264 desc/s image by image, 388 with eight in flight).
+    ``max_pixels`` bounds a batch by N x H x W as well (the workspace grows with it); a batch the device cannot allocate is halved and retried."""
     device = torch.device(device) if device is not None else getattr(net, "device", torch.device("cpu"))
     if batched is None:
         batched = device.type == "cuda"
@@ -57,8 +58,9 @@ def extract_vectors(net, images, device=None, batched=None, max_batch=32, concur
                 groups.setdefault(tuple(x.shape[1:]), []).append(i)
             jobs = []
             for shape, idx in groups.items():                       # dict order = first appearance: deterministic
-                for lo in range(0, len(idx), max_batch):
-                    jobs.append(idx[lo:lo + max_batch])
+                step = max_batch if max_pixels is None else max(1, min(max_batch, int(max_pixels) // max(1, shape[-1] * shape[-2])))
+                for lo in range(0, len(idx), step):
+                    jobs.append(idx[lo:lo + step])
             # small jobs (sizes that occur once or twice) are handed over together, up to ``concurrent`` images: their forwards run side by side on the device
             many = getattr(net, "forward_list", None)
             at = 0
@@ -70,7 +72,18 @@ def extract_vectors(net, images, device=None, batched=None, max_batch=32, concur
                         take += 1
                 parts = jobs[at:at + take]
                 batches = [torch.cat([items[i].to(device) for i in part], 0) for part in parts]
-                outs = many(batches) if take > 1 else [net(batches[0])]
+                try:
+                    outs = many(batches) if take > 1 else [net(batches[0])]
+                except (RuntimeError, MemoryError) as err:          # a batch the device cannot allocate: its halves take its place in the job list
+                    text = str(err).lower()
+                    big = max(range(take), key=lambda k: len(parts[k]))
+                    if len(parts[big]) == 1 or not (isinstance(err, torch.cuda.OutOfMemoryError) or "out of memory" in text or "hipmalloc" in text):
+                        raise
+                    del batches
+                    torch.cuda.empty_cache()
+                    half = len(parts[big]) // 2
+                    jobs[at + big:at + big + 1] = [parts[big][:half], parts[big][half:]]
+                    continue
                 for part, out in zip(parts, outs):
                     out = out.detach().float().reshape(-1, len(part))   # (D,) for one image, D x n otherwise
                     for j, i in enumerate(part):

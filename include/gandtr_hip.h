@@ -136,9 +136,12 @@ int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);
 int gdt_net_set_profiling(gdt_net* net, int enable);
 int gdt_net_profile_read(gdt_net* net, int max_ops, int* n_ops, int* kinds, int* tile_n, double* ms, double* flops);
 /* ... and the ALGORITHMIC HBM bytes of each op of that forward (conv ops: input once -- a strided 1x1 conv only the pixels it samples --,
- * output once, residual once, fp16 weights once; a fused launch is booked on its first op without the tensors that never exist):
+ * output once, residual once, fp16 weights once; a fused launch is booked on its first op without the tensors that never exist; a conv that
+ * applies its producer's InstanceNorm while staging also counts the block residual it adds and the normalised tensor it writes back):
  * the numerator of bench.py's HBM view of the Bottleneck 1x1 convs (SURVEY.md section 8d "compulsory bytes"). */
-int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, double* bytes);
+int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, int* n_ops, double* bytes);
+/* number of ops of the graph (= entries the two profile readers return; size the buffers with it) */
+int gdt_net_num_ops(gdt_net* net);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Stand-alone descriptor ops (device fp32 buffers)

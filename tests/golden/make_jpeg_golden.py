@@ -81,6 +81,9 @@ CASES = [  # name, (w, h), gray (True) / four-component kind, save options
     ("cmyk_no_adobe", (36, 28), "noadobe", dict(quality=88)),
     ("pcmyk_q80", (48, 40), "cmyk", dict(quality=80, progressive=True)),
     ("pycck_sub2", (52, 36), "ycck", dict(quality=82, subsampling=2, progressive=True)),
+    # progressive four-component files WITH restart intervals (round 5, ADVICE r4: all four DC predictors are reset at a restart)
+    ("pcmyk_restart", (44, 36), "cmyk", dict(quality=84, progressive=True, restart_marker_blocks=3)),
+    ("pycck_sub2_restart", (52, 36), "ycck", dict(quality=82, subsampling=2, progressive=True, restart_marker_blocks=2)),
 ]
 
 

@@ -163,38 +163,6 @@ def test_halo_c_transposed(cuda_device, cin, cout, norm, res):
     assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 4e-4
 
 
-@pytest.mark.parametrize("cin,cout,norm,res", [(256, 128, False, False), (256, 128, True, True), (128, 64, True, False)])
-def test_ct_c16_opt_in_kernel(cuda_device, monkeypatch, cin, cout, norm, res):
-    """conv_ct_c16.hip (the transposed conv on the 16 x 16 MFMA shapes; opt-in, GDT_CONV_CT_C16=1) against fp64: same cases and gates as
-    test_halo_c_transposed, and the profile shows that kernel (variant 981256) ran"""
-    monkeypatch.setenv("GDT_CONV_CT_C16", "1")
-    net = HipNet(cuda_device, "f16c")
-    t = net.input(3)
-    t0 = net.conv(t, _g(0, "w0", (cin, 3, 1, 1), 0.7))
-    t = t0
-    if norm:
-        r = net.conv(t0, _g(0, "w1", (cin, cin, 1, 1), 0.06)) if res else -1
-        t = net.instance_norm(t0, relu=not res, residual=r)
-    wt, bias = _g(0, "w", (cin, cout, 3, 3), 0.05), _g(0, "b", (cout,), 0.2)
-    out = net.conv(t, wt, bias, stride=2, pad=1, transposed=True)
-    o2 = net.instance_norm(out, relu=True)
-    taps = [net.output_nchw(out), net.output_nchw(o2)]
-    net.finalize()
-    x = synth.synth_input(1, (8, 3, 64, 64))
-    net.set_profiling(True)
-    outs = net.forward(x.to(cuda_device))
-    torch.cuda.synchronize()
-    assert 981256 in [v for k, v, ms, fl in net.profile() if k == 1]
-    a0 = F.conv2d(x.double(), _g(0, "w0", (cin, 3, 1, 1), 0.7).double())
-    a = a0
-    if norm:
-        a = F.instance_norm(a0, eps=1e-5)
-        a = a + F.conv2d(a0, _g(0, "w1", (cin, cin, 1, 1), 0.06).double()) if res else F.relu(a)
-    ref = F.conv_transpose2d(a, wt.double(), bias.double(), stride=2, padding=1, output_padding=1)
-    assert _rel(outs[taps[0]].double().cpu(), ref) < 3e-4
-    assert _rel(outs[taps[1]].double().cpu(), F.relu(F.instance_norm(ref, eps=1e-5))) < 4e-4
-
-
 @pytest.mark.parametrize("cin,cout,norm,tapped,bn", [(64, 128, False, False, False), (64, 128, True, False, False), (128, 256, True, True, False),
                                                       (64, 128, False, False, True)])
 def test_halo_c_stride2(cuda_device, cin, cout, norm, tapped, bn):
@@ -561,3 +529,9 @@ def test_infer_stage_groups_equal_sizes_on_the_device(cuda_device, tmp_path, mon
     for g, l, x in zip(grouped, loop, items):
         assert g.shape == l.shape == (x.shape[1], x.shape[2], 3)
         assert float(np.abs(g - l).max()) < 2e-3          # pictures in [0, 1]; batch 1 and batch 4-7 pick other kernel variants (f16x3 generic vs compensated patch kernels)
+    # a batch is bounded by its pixels, too (here: two 64 x 64 items, one 64 x 96 item per forward) -- same pictures, input order kept
+    monkeypatch.setenv("GANDTR_INFER_BATCH", "64")
+    monkeypatch.setenv("GANDTR_INFER_PIXELS", str(2 * 64 * 64))
+    _, capped = infer(params, (items,))
+    for c, l in zip(capped, loop):
+        assert c.shape == l.shape and float(np.abs(c - l).max()) < 2e-3

@@ -222,3 +222,125 @@ def test_progressive_coefficient_decoder_on_the_host():
         for cut in (len(blob) // 2, len(blob) - 2):
             rc = lib.gdt_jpeg_progressive_coefficients(blob[:cut], cut, ctypes.byref(p.info), coef.ctypes.data)
             assert rc != 0 and b"truncated" in lib.gdt_last_error()
+
+
+def _dht_segments(blob):
+    """(offset of the 0xFF of every DHT marker segment, its length field) in file order"""
+    out, pos = [], 2
+    while pos + 4 <= len(blob):
+        assert blob[pos] == 0xFF
+        m = blob[pos + 1]
+        if m == 0xD9:
+            break
+        ln = (blob[pos + 2] << 8) | blob[pos + 3]
+        if m == 0xC4:
+            out.append((pos, ln))
+        if m == 0xDA:                                   # skip the entropy-coded data up to the next marker that is not RSTn / stuffing
+            pos += 2 + ln
+            while pos + 1 < len(blob) and not (blob[pos] == 0xFF and blob[pos + 1] != 0 and not 0xD0 <= blob[pos + 1] <= 0xD7 and blob[pos + 1] != 0xFF):
+                pos += 1
+            continue
+        pos += 2 + ln
+    return out
+
+
+def test_oversubscribed_huffman_tables_are_refused():
+    """a DHT whose 16 length counts do not form a prefix code (e.g. all symbols at length 1) used to pass gdt_jpeg_parse and
+    then index far past the 512-entry look-up table of the host progressive decoder (stack smash).  The counts are now checked the way the
+    library does (codes of length l fit l bits, none all ones): tables 0 / 1 and 2 / 3, before the first scan (parser) and between the scans
+    (coefficient decoder), baseline files too."""
+    lib = _hip.load()
+    rng = np.random.RandomState(11)
+    arr = rng.randint(0, 256, (48, 64, 3), dtype=np.uint8)
+
+    def smash(blob, seg_index, th=None):
+        b = bytearray(blob)
+        pos, ln = _dht_segments(blob)[seg_index]
+        q = pos + 4                                       # first table of the segment: Tc/Th, 16 counts, symbols
+        total = sum(b[q + 1:q + 17])
+        assert 2 <= total <= 255
+        b[q + 1:q + 17] = bytes([total] + [0] * 15)      # every symbol a code of length 1
+        if th is not None:
+            b[q] = (b[q] & 0xF0) | th
+        return bytes(b)
+
+    base = _encode(arr, quality=80, subsampling=2)
+    prog = _encode(arr, quality=80, subsampling=2, progressive=True)
+    assert len(_dht_segments(base)) >= 1 and len(_dht_segments(prog)) >= 2
+    first_scan = prog.index(b"\xff\xda")
+    assert any(pos < first_scan for pos, _ in _dht_segments(prog)) and any(pos > first_scan for pos, _ in _dht_segments(prog)), \
+        "Pillow's progressive files define tables before the first scan and between the scans"
+
+    def ours(blob):
+        """None if the file decodes on the host side, else the error text (a crash would end the test run)"""
+        try:
+            p = jpeg.parse(blob)
+        except ValueError as e:
+            return str(e)
+        if not p.info.progressive:
+            return None
+        coef = np.zeros(p.info.mcus_x * p.info.mcus_y * p.info.blocks_per_mcu * 64, dtype=np.int16)
+        rc = lib.gdt_jpeg_progressive_coefficients(blob, len(blob), ctypes.byref(p.info), coef.ctypes.data)
+        return None if rc == 0 else lib.gdt_last_error().decode()
+
+    def pillow_ok(blob):
+        try:
+            Image.open(io.BytesIO(blob)).convert("RGB")
+            return True
+        except Exception:
+            return False
+
+    # a table a scan USES: refused with the reason, as the reference's loader refuses it (the library checks a table when a scan starts)
+    used = [smash(base, i) for i in range(len(_dht_segments(base)))] + [smash(prog, i) for i in range(len(_dht_segments(prog)))]
+    for blob in used:
+        err = ours(blob)
+        assert err is not None and "Huffman" in err, err
+        assert not pillow_ok(blob)
+    # the same broken tables under the numbers 2 / 3 (progressive files may use them; here no scan does, or the scan loses its own table): no crash,
+    # and nothing is accepted that the reference's loader refuses
+    for i in range(len(_dht_segments(prog))):
+        for th in (2, 3):
+            blob = smash(prog, i, th)
+            assert not (ours(blob) is None and not pillow_ok(blob))
+    # ... and USED under those numbers: scan headers re-pointed to table 2 with the DHT that defines it
+    pos, ln = _dht_segments(prog)[0]
+    b = bytearray(smash(prog, 0, th=2))
+    tc = b[pos + 4] >> 4
+    sos = prog.index(b"\xff\xda")
+    ns = b[sos + 4]
+    for c in range(ns):                                   # first scan (DC, interleaved): its table selectors
+        sel = b[sos + 6 + 2 * c]
+        b[sos + 6 + 2 * c] = (sel & 0x0F) | 0x20 if tc == 0 else (sel & 0xF0) | 0x02
+    err = ours(bytes(b))
+    assert err is not None and "Huffman" in err, err
+    # a complete code with an all-ones codeword (2 symbols of length 1) is refused as the library refuses it
+    b = bytearray(base)
+    pos, _ = _dht_segments(base)[0]
+    b[pos + 5:pos + 21] = bytes([2] + [0] * 15)
+    err = ours(bytes(b))
+    assert err is not None and not pillow_ok(bytes(b))
+
+
+def test_progressive_four_component_restart_resets_all_predictors():
+    """the DC predictor of the FOURTH component was not reset at restart markers of a progressive scan.  The same CMYK picture
+    coded with and without restart intervals carries the same coefficients."""
+    lib = _hip.load()
+    rng = np.random.RandomState(5)
+    small = rng.randint(0, 256, (9, 11, 4), dtype=np.uint8)
+    img = Image.fromarray(small, "CMYK").resize((44, 36), Image.BICUBIC)
+
+    def coefs(**kw):
+        buf = io.BytesIO()
+        img.save(buf, "JPEG", quality=84, progressive=True, **kw)
+        blob = buf.getvalue()
+        p = jpeg.parse(blob)
+        assert p.info.ncomp == 4 and p.info.progressive
+        c = np.zeros(p.info.mcus_x * p.info.mcus_y * p.info.blocks_per_mcu * 64, dtype=np.int16)
+        assert lib.gdt_jpeg_progressive_coefficients(blob, len(blob), ctypes.byref(p.info), c.ctypes.data) == 0, lib.gdt_last_error()
+        return c.reshape(-1, p.info.blocks_per_mcu, 64), p.info.restart_interval
+
+    plain, r0 = coefs()
+    for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1), dict(restart_marker_blocks=1)):
+        with_rst, r1 = coefs(**kw)
+        assert r0 == 0 and r1 > 0
+        assert np.array_equal(plain, with_rst), [int((plain[:, c] != with_rst[:, c]).sum()) for c in range(plain.shape[1])]

@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; shift 2
 cd "$(dirname "$0")/../gandtr_amd/csrc"
 mkdir -p ../../tmpbin
 OBJ=/tmp/variant_${NAME}_$(basename $SRC .hip).o
-EXTRA=""; case "$(basename $SRC)" in conv3x3_halo_c16.hip|conv_ct_c16.hip|conv_s2_c16.hip) EXTRA="-mllvm -pragma-unroll-threshold=400000";; esac; [ -n "" ] && EXTRA="-mllvm -pragma-unroll-threshold=400000"
+EXTRA=""; case "$(basename $SRC)" in conv3x3_halo_c16.hip) EXTRA="-mllvm -pragma-unroll-threshold=400000";; esac      # (as in the Makefile)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result $EXTRA "$@" -c $SRC -o $OBJ
 OBJS=$(ls *.o | grep -v "^$(basename $SRC .hip).o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tmpbin/lib_${NAME}.so $OBJS $OBJ
