@@ -4,10 +4,11 @@ tests/ (and nothing under gandtr_amd/).
 * scores / ranks:      mdir/components/optim/score/cirscore.py:71-73   (numpy dot + argsort)
 * negative selection:  mdir/external/cirtorch/datasets/traindataset.py:246-279 (`TuplesDataset._search_hard_negatives`)
 
-Pinning: the selection is integer bookkeeping on a ranking; `tests/test_oracle_retrieval.py` checks this restatement on hand-made cases whose
-answer follows from the text of the reference loop (query cluster excluded, at most one image per cluster, order of the ranking kept) and
-against a line-by-line torch transcription of the loop run on the same random data.  The reference class itself needs its pickled training
-database (`TuplesDataset.__init__` loads `db_fn`, absent offline), so no fixture generated BY the reference exists for this row.
+Pinning: `tests/golden/hard_negatives.npz` holds outputs of the reference's OWN method -- `TuplesDataset._search_hard_negatives` called unbound on
+a namespace carrying `clusters` and `nnum`, the only attributes it reads (tests/golden/make_golden.py, section 9; the class's `__init__` wants the
+pickled training database, which the method does not need) -- for four seeded cases (random unit vectors; queries whose own cluster fills the top of
+the ranking; few clusters).  `tests/test_oracle_retrieval.py` checks this restatement against them (indices exactly, distances to float32 rounding)
+and on hand-made cases whose answer follows from the text of the reference loop.
 """
 import numpy as np
 

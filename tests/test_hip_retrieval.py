@@ -77,3 +77,16 @@ def test_hard_negative_selection_runs_out_of_clusters(cuda_device):
     poolvecs, qvecs = _unit(5, 64, 50), _unit(6, 64, 3)
     with pytest.raises(IndexError):
         retrieval.search_hard_negatives([0, 1, 2], qvecs.to(cuda_device), list(range(10, 60)), poolvecs.to(cuda_device), [0, 1, 2] * 20, 5)
+
+
+def test_hard_negative_selection_against_the_reference_fixture(cuda_device):
+    """`retrieval.search_hard_negatives` (scores, sort and selection on the device) against tests/golden/hard_negatives.npz = outputs of the reference's own
+    `TuplesDataset._search_hard_negatives` (traindataset.py:246-279; make_golden.py section 9): the same images in the same order, the same distances"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_negatives.npz"))
+    for k in range(int(g["cases"])):
+        c = {key: g["c%d_%s" % (k, key)] for key in ("poolvecs", "qvecs", "clusters", "idxs2images", "qidxs", "nidxs", "ndist")}
+        nidxs, stats = retrieval.search_hard_negatives(c["qidxs"].tolist(), torch.from_numpy(c["qvecs"]).to(cuda_device), c["idxs2images"].tolist(),
+                                                       torch.from_numpy(c["poolvecs"]).to(cuda_device), c["clusters"].tolist(), int(g["c%d_nnum" % k]))
+        assert nidxs == c["nidxs"].tolist(), k
+        assert np.allclose(stats["average_negative_distance"], c["ndist"], rtol=1e-5, atol=1e-6), k

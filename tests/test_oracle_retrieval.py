@@ -1,5 +1,8 @@
-"""The CPU restatement of the reference's hard-negative selection (oracle/retrieval_oracle.py) on cases whose answer follows from the text of
-traindataset.py:256-275, and against a torch transcription of that loop (torch.mm / torch.sort, as the reference writes it)."""
+"""The CPU restatement of the reference's hard-negative selection (oracle/retrieval_oracle.py) against the fixture the reference's own
+`TuplesDataset._search_hard_negatives` produced (tests/golden/hard_negatives.npz, make_golden.py section 9), on cases whose answer follows from the
+text of traindataset.py:256-275, and against a torch transcription of that loop (torch.mm / torch.sort, as the reference writes it)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -51,3 +54,26 @@ def test_against_torch_transcription_of_the_loop(seed):
     want = _reference_loop_torch(qidxs, torch.from_numpy(qvecs), idxs2images, torch.from_numpy(poolvecs), clusters, 5)
     got, dist = R.search_hard_negatives(qidxs, qvecs, idxs2images, poolvecs, clusters, 5)
     assert got == want and len(dist) == nq * 5
+
+
+def _fixture():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_negatives.npz"))
+
+
+def test_against_the_reference_methods_own_output():
+    """the fixture: outputs of the reference's `_search_hard_negatives` itself (called unbound, make_golden.py section 9)"""
+    g = _fixture()
+    n = int(g["cases"])
+    assert n >= 3
+    skipped_own_cluster = 0
+    for k in range(n):
+        c = {key: g["c%d_%s" % (k, key)] for key in ("poolvecs", "qvecs", "clusters", "idxs2images", "qidxs", "nidxs", "ndist")}
+        nnum = int(g["c%d_nnum" % k])
+        got, dist = R.search_hard_negatives(c["qidxs"].tolist(), c["qvecs"], c["idxs2images"].tolist(), c["poolvecs"], c["clusters"].tolist(), nnum)
+        assert got == c["nidxs"].tolist(), k
+        assert np.allclose(dist, c["ndist"], rtol=2e-6, atol=1e-7), k           # (the reference sums the squares in float32)
+        # the case is worth its name: count the top-ranked candidates the rules had to skip
+        _, ranks = R.scores_and_ranks(c["poolvecs"], c["qvecs"])
+        for q in range(len(c["qidxs"])):
+            skipped_own_cluster += int(c["clusters"][c["idxs2images"][ranks[0, q]]] == c["clusters"][c["qidxs"][q]])
+    assert skipped_own_cluster >= 6          # case 1's first six queries: the best-scoring pool image belongs to the query's own cluster
