@@ -120,9 +120,11 @@ def sharded_main(args):
     out = {"n_gpus": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "dry_run": dry}
     tmp = tempfile.mkdtemp()
     steps, warmup = (1, 0) if dry else (args.steps, 1)
+    small = dry or args.small          # tiny images: the CPU rehearsal, or the GPU test of the RCCL path (tests/test_hip_rccl_world1.py)
+    check = dry or args.check          # gathered == single-process result over the same chunks, bit for bit, on EVERY rank
     with torch.no_grad():
         # ---- c3: multi-scale + whitening, batch-sharded, one all-gather
-        per_rank, side = (2, 64) if dry else (8, 1024)
+        per_rank, side = ((2, 64) if dry else (2, 256)) if small else (8, 1024)
         # (--global-batch: a global batch that the ranks do not divide -- contiguous chunks of ceil(N / world) images, the last chunk short or
         #  empty, zero-padded for the collective and trimmed afterwards: sharding.chunk_bounds / all_gather_descriptors)
         n_glob = args.global_batch if args.global_batch else per_rank * world
@@ -134,15 +136,15 @@ def sharded_main(args):
             got = sharding.embed_sharded(net, x)
             rec = {"descriptors_per_s": round(n_glob / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": n_glob,
                    "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
-            if dry:            # the multi-GPU contract: gathered == single-process result over the same chunks, bit for bit, on EVERY rank
+            if check:          # the multi-GPU contract: gathered == single-process result over the same chunks, bit for bit, on EVERY rank
                 ref = sharding.descriptors_in_chunks(net, x, per_rank)
-                ok = torch.tensor([int(torch.equal(got, ref))])
+                ok = torch.tensor([int(torch.equal(got, ref))], device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 rec["sharded_equals_single_process_bitwise"] = bool(ok.item())
             out["c3_gem_resnet101_ms_%s" % tag] = rec
             del net
         # ---- c4: augment -> embed, 128 images per rank, descriptors gathered, generator outputs not
-        per_rank, side = (2, 32) if dry else (128, 256)
+        per_rank, side = ((2, 32) if dry else (8, 64)) if small else (128, 256)
         n_glob = args.global_batch if args.global_batch else per_rank * world
         per_rank = (n_glob + world - 1) // world
         x = synth.synth_input(5, (n_glob, 3, side, side), 1.0).to(dev)
@@ -151,9 +153,9 @@ def sharded_main(args):
         got = sharding.embed_sharded(chain, x)
         rec = {"images_per_s": round(n_glob / dt, 1), "ms_per_step": round(dt * 1e3, 2), "global_batch": n_glob,
                "image": "%dx%d" % (side, side), "gathered": list(got.shape)}
-        if dry:
+        if check:
             ref = sharding.descriptors_in_chunks(chain, x, per_rank)
-            ok = torch.tensor([int(torch.equal(got, ref))])
+            ok = torch.tensor([int(torch.equal(got, ref))], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             rec["sharded_equals_single_process_bitwise"] = bool(ok.item())
         out["c4_augment_then_embed"] = rec
@@ -374,6 +376,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--dry-run", action="store_true", help="configs 4 / 5 sharded over N gloo ranks on the CPU, tiny images, bitwise check against one process")
     ap.add_argument("--global-batch", type=int, default=0, help="sharded configs: images in the global batch (default: 8 / 128 per rank; any N, the ranks need not divide it)")
+    ap.add_argument("--small", action="store_true", help="sharded configs on the GPU with small images (2 x 256^2 / 8 x 64^2 per rank): the RCCL path's functional test")
+    ap.add_argument("--check", action="store_true", help="sharded configs: every rank compares the gathered D x N matrix with the single-process result over the same chunks, bit for bit")
     ap.add_argument("--sharded", action="store_true", help="run the sharded configs 4 / 5 even with --gpus 1 (one rank: the same code path, RCCL world size 1)")
     a = ap.parse_args()
     if "RANK" in os.environ and (a.gpus > 1 or a.dry_run or a.sharded):
