@@ -148,6 +148,8 @@ def kernel_name(variant):
         return "conv_igemm_rb_kernel<%d>" % (variant - 940000)
     if variant >= 939000:
         return "conv3x3_expand_rb_kernel<%d>" % ((variant - 939000) * 8)   # Bottleneck 3x3 + expand 1x1 + residual in one launch
+    if variant >= 938000:
+        return "conv3x3_expand_rb_kernel<%d>[+next reduce]" % ((variant - 938000) * 8)   # ... + the next block's reduce conv (phase C)
     if variant >= 935000:                                   # (+1: the projection-shortcut form)
         return "conv_bneck_kernel<%d>%s" % ((variant - 935000) & ~1, "[projection]" if (variant & 1) else "")
     if variant >= 930000:
@@ -172,7 +174,7 @@ def pmc_traffic(kernel, key):
         with open(os.path.join(ROOT, "profiles", key)) as f:
             doc = json.load(f)
         # (the profiler names conv3x3_expand_rb_kernel by its patch-height template argument, bench.py by the expand conv's channel count)
-        alias = {"conv3x3_expand_rb_kernel<1024>": "conv3x3_expand_rb_kernel<8>"}
+        alias = {"conv3x3_expand_rb_kernel<1024>": "conv3x3_expand_rb_kernel<8>", "conv3x3_expand_rb_kernel<1024>[+next reduce]": "conv3x3_expand_rb_kernel<8, true>"}
         ks = doc["kernels"]
         return (ks[kernel] if kernel in ks else ks[alias[kernel]])["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):

@@ -21,6 +21,22 @@
 //   Every lane-derived address of phase B is made from an opaque lane copy where it is used: hoisted out of the pass loop they were spilled (82 registers in
 //   the first build), and a scratch reload is a vector-memory wait behind the HBM stream.
 //
+//   phase C (round 5, CHAIN form, PH = 8): the NEXT block's reduce conv  r' = ReLU(BN(W_r . y))  (1x1, x_cout -> 256: torchvision Bottleneck.conv1 of the following
+//                  block) on the tile this workgroup has just written.  Its accumulators (128 pixels x 64 channels per wave = 128 registers) cannot live beside
+//                  phase B's (the K of this GEMM is produced pass by pass, so they would have to stay live through all of phase B: 256 accumulator registers + 100 of
+//                  operands against the 256 a wave has at two waves per SIMD; one wave per SIMD would hold them but gives up the second workgroup that overlaps the
+//                  phases), and the LDS has no room for the tile of y (256 KB).  So the tile's y lines are read back -- written microseconds ago by this very
+//                  workgroup, they come from L2 / the Infinity Cache, not from HBM -- in 64-channel chunks through registers into two of the (dead) t planes, the
+//                  K-loop is conv1x1_rb's (W_r fragments through the four-slot ring, activations one chunk ahead), r' leaves through the wave-private patches as
+//                  whole 128-byte lines.  The separate reduce launch (0.08 ms per block, 268 MB of y read back from HBM) is gone.
+//                  Measured (round 5): the chained launch takes 0.305 ms against 0.227 + 0.083 ms for the two launches it replaces -- a tie in time (2.40 k
+//                  descriptors/s either way), 5.6 GB less HBM traffic per forward and 21 launches fewer.  Stamps per tile and wave: phase A 75 k cycles (36.9 k of
+//                  MFMA time: two workgroups share each SIMD), hand-over 6 k, phase B k-loops 33 k, phase B epilogues 44 k, phase C 75 k (16.4 k of MFMA time), next
+//                  tile's first chunk 12 k.  Ablations of phase C (timing only): without its y loads 59 k, without its weight re-loads 60 k, without its per-chunk
+//                  barriers 72 k, with none of the three 46 k (= prologue + epilogue + a k-loop like phase B's).  The launch as a whole keeps the matrix pipes 58 %
+//                  busy (70 k of MFMA time per tile in the 120 k cycles a CU spends per tile); what is missing is a third wave per SIMD to issue while two wait,
+//                  and 256-register waves leave room for two.
+//
 // Measured (GeM-ResNet-101, 32 x 1024^2, layer3: 131 072 pixels per block): layer by layer 0.128 + 0.143 ms; one 512-thread workgroup per CU on 16 x 16
 // patches 0.240 ms; two 256-thread workgroups per CU on 8 x 16 patches, the second started 30 us late, 0.222 ms (stamps: phase A 99 k cycles per 256 pixels
 // without a byte of HBM traffic, phase B 87 k cycles for 1 MB per tile = the CU's share of ~5 TB/s: with every CU in the same phase at the same time the two
@@ -28,9 +44,19 @@
 // limit, like the generator's).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gdt_common.h"
+
+#ifndef GDT_XEXP_CABL
+#define GDT_XEXP_CABL 0        // timing-only ablations of phase C (results are wrong by design): 1 no y loads / LDS writes, 2 no per-chunk barrier, 4 no weight re-loads
+#endif
+#ifndef GDT_XEXP_CDEPTH
+#define GDT_XEXP_CDEPTH 1      // phase C: register sets of y chunks in flight (1, 3 or 5).  Measured: 3 sets change nothing (phase C 75.4 k cycles per tile either way,
+                               // 7-11 spilled registers) -- vector loads retire in order, so the wait for a weight fragment issued after a y load also waits for that y
+                               // load, however early the NEXT one was requested: the latency a y line may take is the depth of the weight ring (four k-steps)
+#endif
 
 namespace {
 
@@ -57,9 +83,12 @@ template <int PH> struct Geo {
 
 struct TileAt { int n, y0, x0; bool valid; };
 
-template <int PH>
+struct Pend4 { f16x8 v[4]; };
+
+template <int PH, bool CHAIN = false>
 __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_rb_kernel(const ConvLaunch d, const int ntiles) {
     using G = Geo<PH>;
+    static_assert(!CHAIN || PH == 8, "the chained form exists for the two-workgroups-per-CU layout only");
     constexpr int NT = G::NT, RPR = G::RPR, HROWS = G::HROWS, HROWS_PAD = G::HROWS_PAD, A_BYTES = G::A_BYTES, NR = G::NR, PLANE = G::PLANE, PATCH_OFF = G::PATCH_OFF;
     (void)NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,6 +168,7 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
         for (int j = 0; j < TN; ++j) b[kk][j] = *(const f16x8*)(we + (long)j * NKSE * 512 + lane_off);
     };
 
+    constexpr int NKSR = 1024 / 16;                                                // (CHAIN: K of the next block's reduce conv = x_cout = 1024)
     // ---- fragment addresses
     const int fr = lane & 31, fh = lane >> 5;
     int vt[3];                                                                      // phase A: per tap column (the swizzle depends on px + tx)
@@ -158,7 +188,7 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
     __syncthreads();
 
 #ifdef GDT_XEXP_STAMP
-    unsigned long long st_a = 0, st_ho = 0, st_bk = 0, st_be = 0, st_nx = 0, st_t = __builtin_amdgcn_s_memtime(), st_n = 0;
+    unsigned long long st_a = 0, st_ho = 0, st_bk = 0, st_be = 0, st_nx = 0, st_c = 0, st_t = __builtin_amdgcn_s_memtime(), st_n = 0;
     const unsigned long long st_begin = st_t;
 #define GDT_STAMP(acc_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - st_t; st_t = now_; }
 #else
@@ -322,9 +352,10 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);
                 if (ks + 4 < NKSE) load_be(kk, pass, ks + 4);
                 else {
-                    // next pass's first k-steps, or W_3's first step for the next tile (uniform select: the loop stays straight-line)
-                    const f16* nb = lastp ? w3 + (long)kk * 512 : d.x_w_frag + (long)(((pass + 1) * 8 + wn * 2) * NKSE + kk) * 512;
-                    const long js = lastp ? (long)NKS3 * 512 : (long)NKSE * 512;
+                    // next pass's first k-steps, or W_3's first step for the next tile -- CHAIN: W_r's first k-steps (uniform select: the loop stays straight-line)
+                    const f16* nb = lastp ? (CHAIN ? d.r_w_frag + (long)(wn * 2 * NKSR + kk) * 512 : w3 + (long)kk * 512)
+                                          : d.x_w_frag + (long)(((pass + 1) * 8 + wn * 2) * NKSE + kk) * 512;
+                    const long js = lastp ? (CHAIN ? (long)NKSR * 512 : (long)NKS3 * 512) : (long)NKSE * 512;
                     const unsigned lane_off = lane_off_now();
 #pragma unroll
                     for (int j = 0; j < TN; ++j) b[kk][j] = *(const f16x8*)(nb + j * js + lane_off);
@@ -369,6 +400,121 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
             GDT_STAMP(st_be)
 #endif
         }
+        if (CHAIN) {
+            // ------------------------------------------------------------ phase C: r' = ReLU(W_r . y + b_r) on this tile (the next block's reduce conv)
+            // the y lines of this tile were stored by all four waves: complete (vmcnt) and visible workgroup-wide before anyone reads them back; the same barrier
+            // retires the last reads of the t planes, two of which take the y chunks
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            auto c_load = [&](int chunk) -> Pend4 {
+                Pend4 pp;
+                int lr = lrow, l7 = lane & 7;
+                asm volatile("" : "+v"(lr), "+v"(l7));
+                const int q = l7 ^ ((lr >> 1) & 7);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = r * 32 + lr;                                       // row of the plane = pixel of the 8 x 16 patch
+                    const int yy = min(cur.y0 + (px >> 4), d.H - 1), xx = min(cur.x0 + (px & 15), d.W - 1);      // (pixels past the image: a valid line, its result is not stored)
+                    pp.v[r] = *(const f16x8*)(d.out + (unsigned)((cur.n * d.H + yy) * d.W + xx) * (unsigned)d.x_cout + (unsigned)(chunk * 64 + q * 8));
+                }
+                return pp;
+            };
+            auto c_store = [&](const Pend4& pp, int plane) {
+                int lr = lrow, l7 = lane & 7;
+                asm volatile("" : "+v"(lr), "+v"(l7));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *(f16x8*)(smem + plane * PLANE + (r * 32 + lr) * ROWB + (l7 << 4)) = pp.v[r];
+            };
+            const int vc = opq(fr_e) * ROWB + ((opq(fh_e) ^ ((opq(fr_e) >> 1) & 7)) << 4);
+            auto c_frag = [&](int plane, int i, int kk) -> f16x8 {
+                return *(const f16x8*)(smem + (vc ^ (kk << 5)) + plane * PLANE + i * (32 * ROWB));
+            };
+            // CD register sets take turns (static indices): chunk c + 1 + CD is requested at the end of chunk c and written to LDS in chunk c + CD
+            constexpr int CD = GDT_XEXP_CDEPTH;
+            Pend4 P[CD];
+            { const Pend4 p0 = c_load(0); c_store(p0, 0); }
+#pragma unroll
+            for (int k = 0; k < CD; ++k) P[k] = c_load(k + 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) afr[0][i] = c_frag(0, i, 0);
+            constexpr int NCC = 1024 / 64;                                               // chunks of y
+            auto chunk_step = [&](Pend4& Pk, const int c, auto last_tag) {
+                constexpr bool lastc = decltype(last_tag)::value;
+                const int pl = c & 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cu = kk & 1, nx = cu ^ 1;
+                    if (kk < 3) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) afr[nx][i] = c_frag(pl, i, kk + 1);
+                    }
+                    if (kk == 1 && !lastc && !(GDT_XEXP_CABL & 1)) c_store(Pk, pl ^ 1);      // chunk c + 1
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[kk][j], afr[cu][i], acc[i][j], 0, 0, 0);
+                    if (lastc || !(GDT_XEXP_CABL & 4)) {   // the slot's next use: the same kk of the next chunk -- or W_3's first step for the next tile
+                        const f16* nb = lastc ? w3 + (long)kk * 512 : d.r_w_frag + (long)(wn * 2 * NKSR + (c + 1) * 4 + kk) * 512;
+                        const long js = lastc ? (long)NKS3 * 512 : (long)NKSR * 512;
+                        const unsigned lane_off = lane_off_now();
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[kk][j] = *(const f16x8*)(nb + j * js + lane_off);
+                    }
+                    if (kk == 3 && !lastc && !(GDT_XEXP_CABL & 1)) Pk = c_load(min(c + 1 + CD, NCC - 1));      // behind the weights (in-order vmcnt); past the end: a line nobody uses
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lastc || !(GDT_XEXP_CABL & 2)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!lastc) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) afr[0][i] = c_frag(pl ^ 1, i, 0);
+                }
+            };
+            static_assert((NCC - 1) % CD == 0 && CD >= 1 && CD <= 3, "the register sets take turns over whole groups of chunks + the last one");
+            for (int c0 = 0; c0 + CD < NCC; c0 += CD) {
+#pragma unroll
+                for (int k = 0; k < CD; ++k) chunk_step(P[k], c0 + k, std::false_type());
+            }
+            chunk_step(P[0], NCC - 1, std::true_type());
+            // epilogue: + b_r, ReLU, fp16, per 32-pixel row block through the wave's patch, whole 128-byte lines of r'
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int fre = opq(fr_e), fhe = opq(fh_e);
+                const int wbase = fre * 128 + (((fre >> 1) & 7) << 4) + fhe * 8;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bv = *(const float4*)(d.r_bias + wn * 64 + j * 32 + 8 * g + 4 * fhe);
+                        const f32x16& a = acc[i][j];
+                        f16x4 h;
+                        h[0] = (f16)fmaxf(a[4 * g] + bv.x, 0.f); h[1] = (f16)fmaxf(a[4 * g + 1] + bv.y, 0.f);
+                        h[2] = (f16)fmaxf(a[4 * g + 2] + bv.z, 0.f); h[3] = (f16)fmaxf(a[4 * g + 3] + bv.w, 0.f);
+                        *(f16x4*)((char*)patch + (wbase ^ ((j * 4 + g) << 4))) = h;
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int le = opq(lane_e);
+                    const int px = (le >> 3) + 8 * q, ch = le & 7;
+                    const int y = cur.y0 + 2 * i + (px >> 4), x = cur.x0 + (px & 15);
+                    const f16x8 v = *(const f16x8*)(patch + px * 64 + ((ch ^ ((px >> 1) & 7)) << 3));
+                    if ((y < d.H) & (x < d.W)) *(f16x8*)(d.r_out + (unsigned)((cur.n * d.H + y) * d.W + x) * 256u + (unsigned)(wn * 64 + ch * 8)) = v;
+                }
+            }
+            GDT_STAMP(st_c)
+        }
 #ifdef GDT_XEXP_STAMP
         ++st_n;
 #endif
@@ -387,7 +533,7 @@ __global__ __launch_bounds__(Geo<PH>::NT, PH == 16 ? 1 : 2) void conv3x3_expand_
 #ifdef GDT_XEXP_STAMP
     if (lane == 0 && d.stamp_out) {
         unsigned long long* o = d.stamp_out + ((long)blockIdx.x * G::WAVES + wave) * 8;
-        o[0] = st_a; o[1] = st_ho; o[2] = st_bk; o[3] = st_be; o[4] = st_nx; o[5] = st_n; o[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        o[0] = st_a; o[1] = st_ho; o[2] = st_bk; o[3] = st_be; o[4] = st_nx; o[5] = st_n; o[6] = __builtin_amdgcn_s_memtime() - st_begin; o[7] = st_c;
     }
 #endif
 }
@@ -414,7 +560,13 @@ bool gdt_conv3x3_expand_eligible(const ConvLaunch& d) {
     return tiles * ph >= (long)min_tiles * 16 && useful >= 0.85;
 }
 
-template <int PH>
+// CHAIN form (phase C): the next block's reduce conv -- a 1x1 conv x_cout = 1024 -> 256 with bias and ReLU on the tensor this launch writes
+bool gdt_conv3x3_expand_chain_eligible(const ConvLaunch& d) {
+    const char* e = getenv("GDT_XEXP_CHAIN");                  // 0: the reduce conv stays its own launch (read when a net plans a geometry: A/B inside one process)
+    return !(e && atoi(e) == 0) && xexp_patch_height() == 8 && d.x_cout == 1024 && gdt_conv3x3_expand_eligible(d);
+}
+
+template <int PH, bool CHAIN = false>
 static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
     using G = Geo<PH>;
     ConvLaunch d = d_in;
@@ -424,7 +576,7 @@ static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
     {
         const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
             v = ncu / 8 * 8;
-            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_expand_rb_kernel<PH>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_expand_rb_kernel<PH, CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
             return GDT_OK;
         });
         if (rc != GDT_OK) return rc;
@@ -442,7 +594,7 @@ static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
     if (!stamp_buf) GDT_CHECK_HIP(hipMalloc((void**)&stamp_buf, (size_t)cus * 2 * W * 8 * sizeof(unsigned long long)));
     GDT_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, (size_t)cus * 2 * W * 8 * sizeof(unsigned long long), stream));
     d.stamp_out = stamp_buf;
-    hipLaunchKernelGGL(conv3x3_expand_rb_kernel<PH>, dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, d, tiles);
+    hipLaunchKernelGGL((conv3x3_expand_rb_kernel<PH, CHAIN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, d, tiles);
     if (++stamp_calls % 100 < 4) {
         GDT_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)grid * W * 8);
@@ -450,16 +602,22 @@ static int launch_xexp(const ConvLaunch& d_in, hipStream_t stream) {
         double s[7] = {0, 0, 0, 0, 0, 0, 0};
         for (size_t w = 0; w < (size_t)grid * W; ++w) for (int k = 0; k < 7; ++k) s[k] += (double)h[w * 8 + k];
         const double nw = (double)grid * W, nt = s[5] / nw;
-        fprintf(stderr, "[xexp stamp] PH %d tiles/wave %.1f; per tile: phase A %.0f, hand-over %.0f, phase B k-loops %.0f, phase B epilogues %.0f, next-tile staging %.0f (per wave) cycles; total per wave %.0f\n",
-                PH, nt, s[0] / nw / nt, s[1] / nw / nt, s[2] / nw / nt, s[3] / nw / nt, s[4] / nw, s[6] / nw);
+        double sc = 0;
+        for (size_t w = 0; w < (size_t)grid * W; ++w) sc += (double)h[w * 8 + 7];
+        fprintf(stderr, "[xexp stamp] PH %d chain %d tiles/wave %.1f; per tile: phase A %.0f, hand-over %.0f, phase B k-loops %.0f, phase B epilogues %.0f, phase C %.0f, next-tile staging %.0f (per wave) cycles; total per wave %.0f\n",
+                PH, (int)CHAIN, nt, s[0] / nw / nt, s[1] / nw / nt, s[2] / nw / nt, s[3] / nw / nt, sc / nw / nt, s[4] / nw, s[6] / nw);
     }
 #else
-    hipLaunchKernelGGL(conv3x3_expand_rb_kernel<PH>, dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, d, tiles);
+    hipLaunchKernelGGL((conv3x3_expand_rb_kernel<PH, CHAIN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, d, tiles);
 #endif
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
 
 int gdt_launch_conv3x3_expand(const ConvLaunch& d, hipStream_t stream) {
+    if (d.r_w_frag) {
+        GDT_REQUIRE(d.r_bias && d.r_out && gdt_conv3x3_expand_chain_eligible(d), "chained reduce conv: 1024 -> 256 with bias, 8 x 16 patches");
+        return launch_xexp<8, true>(d, stream);
+    }
     return xexp_patch_height() == 16 ? launch_xexp<16>(d, stream) : launch_xexp<8>(d, stream);
 }

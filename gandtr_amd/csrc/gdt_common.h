@@ -126,6 +126,9 @@ struct ConvLaunch {
     // x_w_frag in the fragment order of w_frag with K = Cout of the 3x3; x_bias: the expand's bias as one weight fragment per 32 channels (lane (c, 0) =
     // { fp16(b), fp16(b - fp16(b)), 0 .. }: it is added by an MFMA against a { 1, 1, 0 .. } pixel operand); `out`, `res` have x_cout channels
     const f16* x_w_frag; const f16* x_bias; int x_cout;
+    // ... CHAIN form: the NEXT block's reduce conv (1x1, x_cout -> 256, bias, ReLU) on the tile just written: r_w_frag in the fragment order of w_frag with K = x_cout,
+    // r_bias [256] fp32, r_out [N][H][W][256]
+    const f16* r_w_frag; const float* r_bias; f16* r_out;
 };
 
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>
@@ -151,6 +154,7 @@ int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_rb_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip (weights streamed into registers)
 bool gdt_conv3x3_expand_eligible(const ConvLaunch& d);     // conv3x3_expand_rb.hip (3x3 + expand 1x1 + residual of a Bottleneck, variant 939000 + x_cout / 8)
 int gdt_launch_conv3x3_expand(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv3x3_expand_chain_eligible(const ConvLaunch& d);   // ... with the next block's reduce conv as a third phase of the same launch (variant 938000 + x_cout / 8)
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_pool2_eligible(const ConvLaunch& d);         // conv_igemm.hip: can this launch (pool2 = 0) take a fused 2x2 max pool?
 bool gdt_conv_halo_ct_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip, transposed form (variant 960256)

@@ -163,6 +163,7 @@ struct Step {
     int bneck_ds;    // ... or {reduce, 1x1 projection shortcut} in either order at i, i + 1 (bneck_a / bneck_ds), i + 2 (3x3), i + 3 (expand + shortcut); -1: identity form
     int bneck_a;     // index of the block's reduce conv (identity form: the step itself)
     bool xexp;       // CONV (3x3): the block's expand conv (op i + 1: 1x1 + residual + ReLU) runs in the same launch on the LDS-resident tile (conv3x3_expand_rb.hip)
+    int xchain;      // ... and the NEXT block's reduce conv (op index; -1: none -- 1x1, C -> 256, ReLU, reading the expand's output) as a third phase of that launch
     bool kcat;       // CONV: expand conv that also computes its projection shortcut (Op::kcat_ds, whose own step is skipped)
     bool direct;     // INPUT + its only consumer, the ResNet stem conv: the conv reads the caller's fp32 NCHW image itself when no resize is asked (conv_stem_pair_kernel)
     int stats_sets;  // CONV with fused statistics: record sets the INORM finalize sums (phase launches, or N tiles of the fused form)
@@ -221,7 +222,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; plan.steps[i].xexp = false; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; plan.steps[i].xexp = false; plan.steps[i].xchain = -1; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -493,6 +494,17 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         d.res = (const f16*)net; d.out = (f16*)net; d.x_cout = c.cd.cout; d.relu = 1;
         if (!gdt_conv3x3_expand_eligible(d)) continue;
         plan.steps[i].xexp = true; plan.steps[i + 1].skip = true;
+        // ... chained with the next block's reduce conv (torchvision Bottleneck.conv1 of the following block): 1x1, stride 1, C -> 256, bias, ReLU, no residual,
+        // reading the tensor this launch writes; its own launch (and its read of that tensor from HBM) goes away
+        int j2 = i + 2;
+        while (j2 < nops && ops[j2].kind == OP_OUT_NCHW) ++j2;          // (feature taps between the blocks read tensors this launch has written: they stay in place)
+        if (j2 < nops) {
+            const Op& a2 = ops[j2];
+            const bool ok = a2.kind == OP_CONV && plain(a2) && a2.cd.kh == 1 && a2.cd.kw == 1 && a2.cd.pad == 0 && a2.cd.relu && a2.res < 0 && a2.in == c.out &&
+                            a2.cd.cin == c.cd.cout && a2.cin_pad == a2.cd.cin && a2.cd.cout == 256 && a2.cout_pad == 256 && a2.kcat_ds < 0 && a2.out >= 0 &&
+                            plan.steps[j2].norm_from < 0 && plan.steps[j2].pool_into < 0 && !plan.steps[j2].skip && !plan.steps[j2].bneck && !plan.steps[j2].kcat;
+            if (ok && gdt_conv3x3_expand_chain_eligible(d)) { plan.steps[i].xchain = j2; plan.steps[j2].skip = true; }
+        }
     }
 
     // ---- pass 2d (fp16 mode): projection shortcut folded into the expand conv (K-concatenated 1x1, conv1x1_rb.hip) where the block did not fuse as a whole
@@ -574,6 +586,11 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
                     Tensor& t = T[ops[i + 1].out];
                     t.bytes = (size_t)N * t.H * t.W * t.C * net->esize();
                     t.off = arena.alloc(t.bytes);
+                    if (st.xchain >= 0) {                     // ... and the next block's reduce output
+                        Tensor& t2 = T[ops[st.xchain].out];
+                        t2.bytes = (size_t)N * t2.H * t2.W * t2.C * net->esize();
+                        t2.off = arena.alloc(t2.bytes);
+                    }
                     break;
                 }
                 if (st.pool_into >= 0) {                      // the conv writes the pooled tensor; its own output never exists
@@ -1494,13 +1511,25 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.x_cout = oc.cd.cout;
                     d.res = tptr(oc.res); d.out = tptr(oc.out);
                     GDT_REQUIRE(gdt_conv3x3_expand_eligible(d), "planned 3x3 + expand launch is not eligible at run time");
+                    if (stp.xchain >= 0) {
+                        const Op& a2 = net->ops[stp.xchain];
+                        d.r_w_frag = (const f16*)(net->dev_blob + a2.phases[0].w_frag_off);
+                        d.r_bias = (const float*)(net->dev_blob + a2.bias_off);
+                        d.r_out = tptr(a2.out);
+                    }
                     rc = gdt_launch_conv3x3_expand(d, st);
                     if (net->profiling) {
-                        net->last_variant[stp.op] = 939000 + oc.cd.cout / 8;
+                        net->last_variant[stp.op] = (stp.xchain >= 0 ? 938000 : 939000) + oc.cd.cout / 8;
                         net->last_flops[stp.op] += net->last_flops[stp.op + 1]; net->last_flops[stp.op + 1] = 0.0;
                         // bytes: the 256-channel tensor between the two convs is neither written nor read
                         const double mid = (double)n * T[o.out].H * T[o.out].W * T[o.out].C * (double)net->esize();
                         net->last_bytes[stp.op] += net->last_bytes[stp.op + 1] - 2.0 * mid; net->last_bytes[stp.op + 1] = 0.0;
+                        if (stp.xchain >= 0) {  // the chained reduce conv: its FLOPs, its output and weights -- its input is the tensor this launch has just written (not counted twice)
+                            const Op& a2 = net->ops[stp.xchain];
+                            const double yb = (double)n * T[a2.in].H * T[a2.in].W * T[a2.in].C * (double)net->esize();
+                            net->last_flops[stp.op] += net->last_flops[stp.xchain]; net->last_flops[stp.xchain] = 0.0;
+                            net->last_bytes[stp.op] += net->last_bytes[stp.xchain] - yb; net->last_bytes[stp.xchain] = 0.0;
+                        }
                     }
                     break;
                 }

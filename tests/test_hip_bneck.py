@@ -155,34 +155,47 @@ def test_projection_shortcut_folded_into_the_expand_conv(cuda_device, stride, ci
 @pytest.mark.parametrize("n,h,w", [(16, 64, 64), (16, 62, 64), (18, 64, 60), (29, 46, 46)], ids=["whole-patches", "ragged-rows", "ragged-columns", "ragged-both-724px-level"])
 def test_fused_3x3_expand_layer3(cuda_device, n, h, w, monkeypatch):
     """ResNet-101 layer3 geometry (C 1024, MID 256: the block does not fit conv_bneck's LDS plan): the 3x3 conv and the expand conv + residual run as ONE launch
-    (conv3x3_expand_rb.hip, variant 939000 + C / 8; the 256-channel tensor between them stays in LDS) -- against fp64 on the same fp16-rounded input with r and t
-    rounded where the kernels round them, on the image borders, against the layer-by-layer kernels of the same build, deterministic."""
+    (conv3x3_expand_rb.hip, variant 939000 + C / 8; the 256-channel tensor between them stays in LDS), and -- round 5 -- the NEXT block's reduce conv runs as a third
+    phase of that launch (variant 938000 + C / 8: `imageretrievalnet.py:189-190`'s Bottleneck chain) -- against fp64 on the same fp16-rounded input with r and t
+    rounded where the kernels round them, on the image borders, against the unchained and the layer-by-layer kernels of the same build, deterministic."""
     C, mid = 1024, 256
-    net, taps, ws = _block_net(cuda_device, C, mid, nblocks=2)
+    net, taps, ws = _block_net(cuda_device, C, mid, nblocks=3)
     x = synth.synth_input(6, (n, 3, h, w))
     net.set_profiling(True)
     outs = net.forward(x.to(cuda_device))
     torch.cuda.synchronize()
     variants = [v for k, v, ms, fl in net.profile() if k == 1]
-    assert variants.count(939000 + C // 8) == 2, variants                  # both blocks: reduce conv + ONE fused launch
-    xin = outs[taps[0]].double().cpu()
-    ref1 = _ref_block(xin, ws[0])
-    got1 = outs[taps[1]].double().cpu()
-    err1 = float((got1 - ref1).abs().max() / ref1.abs().max())
-    ref2 = _ref_block(got1, ws[1])
-    got2 = outs[taps[2]].double().cpu()
-    err2 = float((got2 - ref2).abs().max() / ref2.abs().max())
-    print("3x3 + expand in one launch, C %d mid %d, %d x %d x %d: %.2e, %.2e of fp64 (fp16 output rounding 4.9e-4)" % (C, mid, n, h, w, err1, err2))
-    assert err1 < 1.5e-3 and err2 < 1.5e-3, (err1, err2)
-    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), h - 1), (slice(None), slice(None), slice(None), 0),
-               (slice(None), slice(None), slice(None), w - 1)):
-        assert float((got1[sl] - ref1[sl]).abs().max() / ref1.abs().max()) < 1.5e-3
-    assert torch.equal(outs[taps[2]], net.forward(x.to(cuda_device))[taps[2]])       # deterministic
-    monkeypatch.setenv("GDT_CONV_XEXP", "0")                            # read when a net plans a geometry
-    net2, taps2, _ = _block_net(cuda_device, C, mid, nblocks=2)
+    # three blocks: reduce conv of block 1 on its own, then [3x3 + expand + reduce of block 2], [3x3 + expand + reduce of block 3], [3x3 + expand]
+    assert variants.count(938000 + C // 8) == 2 and variants.count(939000 + C // 8) == 1, variants
+    assert variants.count(945128) == 1, variants                           # ONE separate 1x1 launch (block 1's reduce) besides the input conv
+    prev = outs[taps[0]].double().cpu()
+    refs, gots = [], []
+    for b in range(3):
+        ref = _ref_block(prev, ws[b])                                       # (every block on the previous block's actual fp16 output)
+        got = outs[taps[b + 1]].double().cpu()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        print("3x3 + expand (+ next reduce) in one launch, block %d, C %d mid %d, %d x %d x %d: %.2e of fp64 (fp16 output rounding 4.9e-4)" % (b, C, mid, n, h, w, err))
+        assert err < 1.5e-3, (b, err)
+        for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), h - 1), (slice(None), slice(None), slice(None), 0),
+                   (slice(None), slice(None), slice(None), w - 1)):
+            assert float((got[sl] - ref[sl]).abs().max() / ref.abs().max()) < 1.5e-3
+        refs.append(ref); gots.append(got); prev = got
+    assert torch.equal(outs[taps[3]], net.forward(x.to(cuda_device))[taps[3]])       # deterministic
+    # the chained reduce against its own launch: the same K order on the same MFMA shape -- bit for bit
+    monkeypatch.setenv("GDT_XEXP_CHAIN", "0")                           # read when a net plans a geometry
+    net1, taps1, _ = _block_net(cuda_device, C, mid, nblocks=3)
+    net1.set_profiling(True)
+    outs1 = net1.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    v1 = [v for k, v, ms, fl in net1.profile() if k == 1]
+    assert v1.count(939000 + C // 8) == 3 and (938000 + C // 8) not in v1, v1
+    assert torch.equal(outs1[taps1[3]], outs[taps[3]])
+    monkeypatch.setenv("GDT_CONV_XEXP", "0")
+    net2, taps2, _ = _block_net(cuda_device, C, mid, nblocks=3)
     net2.set_profiling(True)
     outs2 = net2.forward(x.to(cuda_device))
     torch.cuda.synchronize()
-    assert (939000 + C // 8) not in [v for k, v, ms, fl in net2.profile() if k == 1]
-    d = float((outs2[taps2[2]].double() - outs[taps[2]].double()).abs().max() / ref2.abs().max())
-    assert d < 2e-3, d
+    v2 = [v for k, v, ms, fl in net2.profile() if k == 1]
+    assert (939000 + C // 8) not in v2 and (938000 + C // 8) not in v2
+    d = float((outs2[taps2[3]].double() - outs[taps[3]].double()).abs().max() / refs[2].abs().max())
+    assert d < 3e-3, d
