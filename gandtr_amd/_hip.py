@@ -35,6 +35,12 @@ class JpegInfo(ctypes.Structure):
                 ("huff_vals", (ctypes.c_ubyte * 256) * 4), ("progressive", c_int), ("comp_id", c_int * 4), ("adobe_transform", c_int)]
 
 
+class Level(ctypes.Structure):
+    """struct gdt_level (include/gandtr_hip.h): one geometry of gdt_net_forward_levels."""
+    _fields_ = [("x", c_void_p), ("n", c_int), ("h", c_int), ("w", c_int), ("rh", c_int), ("rw", c_int), ("rscale", c_float),
+                ("outputs", POINTER(c_void_p)), ("n_outputs", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 class JpegItem(ctypes.Structure):
     """struct gdt_jpeg_item (include/gandtr_hip.h)."""
     _fields_ = [("info", POINTER(JpegInfo)), ("scan", c_void_p), ("seg_off", POINTER(ctypes.c_uint)), ("dst_hwc", c_void_p)]
@@ -64,6 +70,8 @@ SIGNATURES = {
     "gdt_net_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_size_t)]),
     "gdt_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, POINTER(c_void_p),
                                 c_int, c_void_p, c_size_t, c_void_p]),
+    "gdt_net_forward_levels": (c_int, [c_void_p, POINTER(Level), c_int, c_void_p]),
+    "gdt_net_levels_joined": (c_int, [c_void_p, _IP]),
     "gdt_net_flops": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
     "gdt_net_set_profiling": (c_int, [c_void_p, c_int]),
     "gdt_net_profile_read": (c_int, [c_void_p, c_int, _IP, _IP, _IP, POINTER(c_double), POINTER(c_double)]),

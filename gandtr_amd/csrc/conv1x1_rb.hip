@@ -14,6 +14,7 @@
 //   * ragged M: loads clamp the row to M - 1 (always a valid address), stores are masked.
 // Same operand formats as conv_igemm_rb.hip: fp16 NHWC, weights in MFMA fragment order (ConvLaunch::w_frag), swapped operands
 // (D = W * A^T), wave-private epilogue patches.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -42,8 +43,9 @@ struct Pend { f16x8 v[4]; };
 // then feeds four MFMAs: with two, the weight stream alone asks the full 64 B/clk of the CU's L1 at MFMA rate
 // CAT: K-concatenated second operand (ConvLaunch::in2): K-steps [0, Cin / 64) read `in`, the rest read `in2` at the stride-in2_stride pixel of
 // the output pixel (the row -> (n, oy, ox) split is done once per tile of the staging cursor)
+// (the body takes its workgroup index and grid size as arguments: the multi-geometry entry below runs it per level, gdt_common.h MultiConv)
 template <bool RES, int DEPTH, int TM, bool CAT = false>
-__global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, const int vblocks) {
+__device__ __forceinline__ void conv1x1_rb_body(const ConvLaunch& d, const int vblocks, const int bid, const int gdim) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
         else if (d.dbg & 2) t.tile_m = ntm - 1 - t.tile_m;        // rows from the end (see gdt_launch_conv_1x1_rb)
         return t;
     };
-    int vb = blockIdx.x;
+    int vb = bid;
     TileAt cur = tile_at(vb);
     if (!cur.valid) return;                   // (validity is monotone in vb)
     const int nk = d.Kpad >> 6, nks = d.Kpad >> 4;
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
     auto advance = [&]() {
         if (++s_step == nk) {
             s_step = 0;
-            const TileAt nx = tile_at(s_vb + gridDim.x);
-            if (nx.valid) { s_tile_m = nx.tile_m; s_vb += gridDim.x; set_rows2(); }
+            const TileAt nx = tile_at(s_vb + gdim);
+            if (nx.valid) { s_tile_m = nx.tile_m; s_vb += gdim; set_rows2(); }
         }
     };
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
     f16* patch = (f16*)(smem + C_OFF) + wave * (32 * PCP);
     int so = 0;
     for (;;) {
-        const TileAt nxt = tile_at(vb + gridDim.x);
+        const TileAt nxt = tile_at(vb + gdim);
         f32x16 acc[TM][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -251,20 +253,32 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, c
             }
         }
         if (!nxt.valid) break;
-        cur = nxt; vb += gridDim.x;
+        cur = nxt; vb += gdim;
 #pragma unroll
         for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0);
     }
 }
 
 template <bool RES, int DEPTH, int TM, bool CAT = false>
-int launch_1x1(const ConvLaunch& d, hipStream_t stream) {
+__global__ __launch_bounds__(NT, 2) void conv1x1_rb_kernel(const ConvLaunch d, const int vblocks) {
+    conv1x1_rb_body<RES, DEPTH, TM, CAT>(d, vblocks, blockIdx.x, gridDim.x);
+}
+template <bool RES, int DEPTH, int TM, bool CAT = false>
+__global__ __launch_bounds__(NT, 2) void conv1x1_rb_multi_kernel(const MultiConv m) {
+    const int l = gdt_multi_level(m.nlev, m.prefix, blockIdx.x);
+    conv1x1_rb_body<RES, DEPTH, TM, CAT>(m.lev[l], m.vblocks[l], blockIdx.x - m.prefix[l], m.prefix[l + 1] - m.prefix[l]);
+}
+
+template <bool RES, int DEPTH, int TM, bool CAT = false>
+int launch_1x1(const ConvLaunch* dl, int L, hipStream_t stream) {
+    const ConvLaunch& d = dl[0];
     static GdtPerDevice per_dev;          // (hipFuncSetAttribute is per device: gdt_common.h)
     int slots = 0;
     {
         const int rc = gdt_per_device(per_dev, slots, [](int, int cus, int& v) {
             int per_cu = 0;
             GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv1x1_rb_multi_kernel<RES, DEPTH, TM, CAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
             GDT_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv1x1_rb_kernel<RES, DEPTH, TM, CAT>, NT, LDS_BYTES));
             static const int cap = [] { const char* e = getenv("GDT_CONV_1X1_WPC"); return e ? atoi(e) : 3; }();
             if (per_cu < 1) per_cu = 1;
@@ -273,6 +287,15 @@ int launch_1x1(const ConvLaunch& d, hipStream_t stream) {
             return GDT_OK;
         });
         if (rc != GDT_OK) return rc;
+    }
+    if (L > 1) {
+        MultiConv m;
+        m.nlev = L;
+        for (int l = 0; l < L; ++l) { m.lev[l] = dl[l]; m.vblocks[l] = gdt_grid_for_tiles((dl[l].M + BM - 1) / BM, dl[l].CoutPad / (TM == 4 ? 256 : 128)); }
+        const int grid = gdt_multi_partition(m.prefix, m.vblocks, L, slots);
+        hipLaunchKernelGGL((conv1x1_rb_multi_kernel<RES, DEPTH, TM, CAT>), dim3(grid), dim3(NT), LDS_BYTES, stream, m);
+        GDT_CHECK_HIP(hipGetLastError());
+        return GDT_OK;
     }
     const int vblocks = gdt_grid_for_tiles((d.M + BM - 1) / BM, d.CoutPad / (TM == 4 ? 256 : 128));
     const int grid = vblocks < slots ? vblocks : slots;
@@ -314,23 +337,34 @@ bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d) {
     return (long)((d.M + BM - 1) / BM) * (d.CoutPad / 128) >= 64;
 }
 
-int gdt_launch_conv_1x1_rb(const ConvLaunch& d_in, hipStream_t stream) {
+// `dl[0 .. L)`: the same conv on L independent geometries (the levels of a pyramid) as ONE launch; the instantiation is chosen for the levels together
+int gdt_launch_conv_1x1_rb_levels(const ConvLaunch* dl_in, int L, hipStream_t stream) {
     // Row order: the reduce convs walk their rows from the END.  Their input is what the expand conv of the previous block has just
     // written front to back, so the rows written last -- the ones still in the 256 MB Infinity Cache -- are read first (and the 3x3
     // conv that follows, front to back, starts on the rows THIS launch wrote last).  ResNet-101 batch 32: 1860 -> 1882 descriptors/s;
     // reversing the expand convs instead gives the same, reversing both nothing (GDT_CONV_1X1_REV: 1 reduce, 2 expand, 3 both, 0 none).
     static const int rev = [] { const char* e = getenv("GDT_CONV_1X1_REV"); return e ? atoi(e) : 1; }();
-    ConvLaunch d = d_in;
-    d.dbg = ((rev & 1) && !d.res) || ((rev & 2) && d.res) ? 2 : 0;
-    if (d.in2) return launch_1x1<false, 2, 4, true>(d, stream);
+    GDT_REQUIRE(L >= 1 && L <= GDT_MAX_LEVELS, "1..4 geometries per launch");
+    ConvLaunch dl[GDT_MAX_LEVELS];
+    long wide_tiles = 0;
+    for (int l = 0; l < L; ++l) {
+        dl[l] = dl_in[l];
+        dl[l].dbg = ((rev & 1) && !dl[l].res) || ((rev & 2) && dl[l].res) ? 2 : 0;
+        GDT_REQUIRE(dl[l].Kpad == dl[0].Kpad && dl[l].CoutPad == dl[0].CoutPad && (dl[l].res != nullptr) == (dl[0].res != nullptr) && (dl[l].in2 != nullptr) == (dl[0].in2 != nullptr),
+                    "the geometries of one launch run the same conv");
+        wide_tiles += (long)((dl[l].M + BM - 1) / BM) * (dl[l].CoutPad / 256);
+    }
+    const ConvLaunch& d = dl[0];
+    if (d.in2) return launch_1x1<false, 2, 4, true>(dl, L, stream);
     const int nk = d.Kpad / 64;
     static const int max_depth = [] { const char* e = getenv("GDT_CONV_1X1_DEPTH"); return e ? atoi(e) : 4; }();
     static const int wide = [] { const char* e = getenv("GDT_CONV_1X1_WIDE"); return e ? atoi(e) : 1; }();
-    if (d.res) return nk > 1 ? launch_1x1<true, 2, 2>(d, stream) : launch_1x1<true, 1, 2>(d, stream);
+    if (d.res) return nk > 1 ? launch_1x1<true, 2, 2>(dl, L, stream) : launch_1x1<true, 1, 2>(dl, L, stream);
     // (the 128 x 256 tile halves the weight stream per MFMA but also the number of workgroups: below ~one per CU the 128 x 128 tile fills the chip better)
     static const int wide_min = [] { const char* e = getenv("GDT_CONV_1X1_WIDE_MIN"); return e ? atoi(e) : 256; }();
-    const long wide_tiles = (long)((d.M + BM - 1) / BM) * (d.CoutPad / 256);
-    if (wide && nk > 1 && d.CoutPad % 256 == 0 && wide_tiles >= wide_min) return launch_1x1<false, 2, 4>(d, stream);
-    if (nk % 4 == 0 && max_depth >= 4) return launch_1x1<false, 4, 2>(d, stream);
-    return nk > 1 ? launch_1x1<false, 2, 2>(d, stream) : launch_1x1<false, 1, 2>(d, stream);
+    if (wide && nk > 1 && d.CoutPad % 256 == 0 && wide_tiles >= wide_min) return launch_1x1<false, 2, 4>(dl, L, stream);
+    if (nk % 4 == 0 && max_depth >= 4) return launch_1x1<false, 4, 2>(dl, L, stream);
+    return nk > 1 ? launch_1x1<false, 2, 2>(dl, L, stream) : launch_1x1<false, 1, 2>(dl, L, stream);
 }
+
+int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream) { return gdt_launch_conv_1x1_rb_levels(&d, 1, stream); }

@@ -15,6 +15,7 @@
 //   * the chunk barrier waits with a COUNTED vmcnt (the 4*TN weight loads of the next step stay in flight).
 // The A side (halo staging by LDS-DMA or, with the producer's InstanceNorm folded in, through registers), the swizzle and
 // the epilogue are those of conv3x3_halo.hip.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -87,8 +88,9 @@ struct TileAt { int n, y0, x0, tile_m, tile_n; bool valid; };
 // and a wave skips the (shift, phase) blocks that are all zero; the epilogue scatters column blocks to output pixels
 // (2y + py, 2x + px).  MODE 3 (norm + residual, no write-back) exists for this form: y9 = y8 + IN(.) feeds only the first
 // transposed conv.
+// (the body takes its workgroup index and grid size as arguments: the multi-geometry entry below runs it per level, gdt_common.h MultiConv)
 template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16, bool SINGLE = false>
-__global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
+__device__ __forceinline__ void conv3x3_halo_rb_body(const ConvLaunch& d, const int vblocks, const int bid, const int gdim) {
     constexpr int PH = PHT, BM = PHT * 16;                              // (shadow the 16-row constants of the file scope)
     constexpr bool ALIAS = PHT > 16;                                    // transpose patches inside the consumed halo stage
     static_assert(!SINGLE || (MODE == 0 && !CT && WGM * WGN == 4), "single-stage form: plain input, four waves");
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_r
         t.y0 = (tr / tiles_x) * PH; t.x0 = (tr % tiles_x) << 4;
         return t;
     };
-    int vb = blockIdx.x;
+    int vb = bid;
     TileAt cur = tile_at(vb);
     if (!cur.valid) return;                   // (validity is monotone in vb: nothing later either)
 
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_r
     int so = 0;                   // LDS offset of the halo stage of the current chunk (0 or A_BYTES)
     int slot = 0;                 // (scale, shift) slot of the current tile
     for (;;) {
-        const TileAt nxt = tile_at(vb + gridDim.x);
+        const TileAt nxt = tile_at(vb + gdim);
         if (SINGLE) {                    // the tile's whole halo: every load issued before the first is consumed, then the LDS writes, then the barrier
             Pend pp[NR];
 #pragma unroll
@@ -454,13 +456,50 @@ __global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_r
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        cur = nxt; vb += gridDim.x; slot ^= 1;
+        cur = nxt; vb += gdim; slot ^= 1;
         if (!SINGLE) {
             so = A_BYTES - so;
 #pragma unroll
             for (int i = 0; i < TM; ++i) afr[0][i] = a_frag(so, i, 0, 0, 0);
         }
     }
+}
+
+template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16, bool SINGLE = false>
+__global__ __launch_bounds__(WGM * WGN * 64, SINGLE ? 2 : 1) void conv3x3_halo_rb_kernel(const ConvLaunch d, const int vblocks) {
+    conv3x3_halo_rb_body<BN, WGM, WGN, MODE, CT, PHT, SINGLE>(d, vblocks, blockIdx.x, gridDim.x);
+}
+// plain 3x3 convs only (MODE 0, no transposed / single-stage forms): what the embedders' pyramids run
+template <int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64, 1) void conv3x3_halo_rb_multi_kernel(const MultiConv m) {
+    const int l = gdt_multi_level(m.nlev, m.prefix, blockIdx.x);
+    conv3x3_halo_rb_body<BN, WGM, WGN, 0, false, 16, false>(m.lev[l], m.vblocks[l], blockIdx.x - m.prefix[l], m.prefix[l + 1] - m.prefix[l]);
+}
+
+template <int BN, int WGM, int WGN>
+int launch_rb_multi(const ConvLaunch* dl, int L, hipStream_t stream) {
+    constexpr size_t lds = rb_lds_bytes<BN, 16, false>();
+    static GdtPerDevice per_dev;
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_rb_multi_kernel<BN, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
+    }
+    static const int dbg = [] { const char* e = getenv("GDT_RB_DBG"); return e ? atoi(e) : 0; }();
+    MultiConv m;
+    m.nlev = L;
+    for (int l = 0; l < L; ++l) {
+        m.lev[l] = dl[l]; m.lev[l].dbg = dbg;
+        m.vblocks[l] = gdt_grid_for_tiles(dl[l].N * ((dl[l].W + 15) / 16) * ((dl[l].H + 15) / 16), dl[l].CoutPad / BN);
+    }
+    const int grid = gdt_multi_partition(m.prefix, m.vblocks, L, cus);
+    hipLaunchKernelGGL((conv3x3_halo_rb_multi_kernel<BN, WGM, WGN>), dim3(grid), dim3(WGM * WGN * 64), lds, stream, m);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
 }
 
 template <int BN, int WGM, int WGN, int MODE, bool CT = false, int PHT = 16, bool SINGLE = false>
@@ -533,6 +572,28 @@ int gdt_launch_conv_halo_rb(const ConvLaunch& d_in, hipStream_t stream) {
     }
     if (d.in_res) { GDT_REQUIRE(d.in_out != nullptr, "residual fold without write-back target"); return launch_rb<256, 2, 4, 7>(d, stream); }
     return d.in_out ? launch_rb<256, 2, 4, 5>(d, stream) : launch_rb<256, 2, 4, 1>(d, stream);
+}
+
+// The same plain 3x3 conv (no folded norm, no fused pool, no statistics, 256 output channels per tile) on L independent geometries as ONE launch; false when the
+// levels cannot share a launch (the caller then launches them one by one)
+bool gdt_conv_halo_rb_levels_ok(const ConvLaunch* dl, int L) {
+    if (L < 2 || L > GDT_MAX_LEVELS) return false;
+    for (int l = 0; l < L; ++l) {
+        const ConvLaunch& d = dl[l];
+        if (!gdt_conv_halo_rb_eligible(d) || d.in_norm || d.in_res || d.in_out || d.stats || d.pool2 || d.phase_cout || d.CoutPad % 256 != 0) return false;
+        if (d.CoutPad != dl[0].CoutPad || d.Cin != dl[0].Cin) return false;
+    }
+    return true;
+}
+
+int gdt_launch_conv_halo_rb_levels(const ConvLaunch* dl, int L, hipStream_t stream) {
+    GDT_REQUIRE(gdt_conv_halo_rb_levels_ok(dl, L), "geometries that cannot share a launch");
+    // the tile shape for the levels together (gdt_launch_conv_halo_rb's rule on the summed patch count)
+    static const int split_below = [] { const char* e = getenv("GDT_RB_SPLIT_BELOW"); return e ? atoi(e) : 192; }();
+    long tiles256 = 0;
+    for (int l = 0; l < L; ++l) tiles256 += (long)dl[l].N * ((dl[l].W + 15) / 16) * ((dl[l].H + 15) / 16) * (dl[l].CoutPad / 256);
+    if (narrow_ok() && tiles256 < split_below) return launch_rb_multi<128, 2, 2>(dl, L, stream);
+    return launch_rb_multi<256, 2, 4>(dl, L, stream);
 }
 
 // Transposed form (CT): fused ConvTranspose2d(k3,s2,p1,op1) launch (phase_cout > 0, weights of Op::ctf), 64 or 128 channels per

@@ -25,6 +25,7 @@
 //   issued BEFORE the (HBM) activation loads: vector-memory operations retire in issue order, and a wait for a weight fragment must
 //   not have to sit out a younger HBM miss.
 //   MFMA operands are swapped (D = W A^T): a lane holds 4 consecutive channels of one pixel.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -86,8 +87,17 @@ struct BneckLaunch {
 
 // RAGGED: maps the patches do not tile exactly (real images: H, W arbitrary) -- the last patch row / column hangs over the image: its x loads are clamped, r is
 // zeroed there (as at every image border), residual fetches are clamped and the stores of pixels outside the image are masked off
+// several independent geometries (the levels of a pyramid) in one launch: gdt_common.h MultiConv, here with this kernel's own descriptor
+struct MultiBneck {
+    int nlev;
+    int prefix[GDT_MAX_LEVELS + 1];
+    int ntiles[GDT_MAX_LEVELS];
+    BneckLaunch lev[GDT_MAX_LEVELS];
+};
+
+// (the body takes its workgroup index and grid size as arguments: the multi-geometry entry runs it per level)
 template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
-__global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, const int ntiles) {
+__device__ __forceinline__ void conv_bneck_body(const BneckLaunch& d, const int ntiles, const int bid, const int gdim) {
     using G = Geo<C, MID, PH, CIN, DS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbuf0 = smem;
@@ -101,8 +111,8 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
     const int tiles_x = (d.W + PW - 1) / PW, tiles_y = (d.H + PH - 1) / PH, tpi = tiles_x * tiles_y;
 
     // XCD-chunked persistent schedule (conv_head7.hip): the CUs of one XCD hold neighbouring patches, whose halos overlap in its L2
-    const int per_xcd = (ntiles + 7) >> 3, S = (int)gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (ntiles + 7) >> 3, S = gdim >> 3;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int span_lo = xcd * per_xcd, span_hi = min(span_lo + per_xcd, ntiles);
     int tile = span_lo + slot;
     if (tile >= span_hi) return;
@@ -453,8 +463,45 @@ __global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, con
         lds_barrier();
     }
 #ifdef GDT_BNECK_STAMP
-    if (lane == 0 && d.stamps) { unsigned long long* o = d.stamps + ((size_t)blockIdx.x * NWAVE + wave) * 4; o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; }
+    if (lane == 0 && d.stamps) { unsigned long long* o = d.stamps + ((size_t)bid * NWAVE + wave) * 4; o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[2]; }
 #endif
+}
+
+template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
+__global__ __launch_bounds__(NT) void conv_bneck_kernel(const BneckLaunch d, const int ntiles) {
+    conv_bneck_body<C, MID, PH, CIN, DS, RAGGED>(d, ntiles, blockIdx.x, gridDim.x);
+}
+template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
+__global__ __launch_bounds__(NT) void conv_bneck_multi_kernel(const MultiBneck m) {
+    const int l = gdt_multi_level(m.nlev, m.prefix, blockIdx.x);
+    conv_bneck_body<C, MID, PH, CIN, DS, RAGGED>(m.lev[l], m.ntiles[l], blockIdx.x - m.prefix[l], m.prefix[l + 1] - m.prefix[l]);
+}
+
+template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
+int launch_multi(const BneckLaunch* dl, int L, hipStream_t stream) {
+    using G = Geo<C, MID, PH, CIN, DS>;
+    static GdtPerDevice per_dev;
+    int cus = 0;
+    {
+        const int rc = gdt_per_device(per_dev, cus, [](int, int ncu, int& v) {
+            v = ncu / 8 * 8;
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bneck_multi_kernel<C, MID, PH, CIN, DS, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+            return GDT_OK;
+        });
+        if (rc != GDT_OK) return rc;
+    }
+    MultiBneck m;
+    m.nlev = L;
+    int want[GDT_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) {
+        m.lev[l] = dl[l];
+        m.ntiles[l] = dl[l].N * ((dl[l].W + PW - 1) / PW) * ((dl[l].H + PH - 1) / PH);
+        want[l] = (m.ntiles[l] + 7) / 8 * 8;
+    }
+    const int grid = gdt_multi_partition(m.prefix, want, L, cus);
+    hipLaunchKernelGGL((conv_bneck_multi_kernel<C, MID, PH, CIN, DS, RAGGED>), dim3(grid), dim3(NT), G::LDS, stream, m);
+    GDT_CHECK_HIP(hipGetLastError());
+    return GDT_OK;
 }
 
 template <int C, int MID, int PH, int CIN = C, bool DS = false, bool RAGGED = false>
@@ -521,5 +568,25 @@ int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f
     if (cin == 512 && C == 512 && mid == 128 && !wd) return (H % 8 || W % PW) ? launch<512, 128, 8, 512, false, true>(d, stream) : launch<512, 128, 8>(d, stream);
     if (cin == 64 && C == 256 && mid == 64 && wd && bd) return (H % 16 || W % PW) ? launch<256, 64, 16, 64, true, true>(d, stream) : launch<256, 64, 16, 64, true>(d, stream);
     gdt_set_error("gdt_launch_bneck: unsupported shape");
+    return GDT_ERR_INVALID;
+}
+
+// The same Bottleneck on L independent geometries (the levels of a pyramid) in ONE launch: every level its own x / y pointers and (N, H, W); the RAGGED
+// instantiation when any level needs it (it is the general form: same results on maps the patches tile exactly)
+int gdt_launch_bneck_levels(const f16* const* x, f16* const* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
+                            const f16* wd, const float* bd, int cin, int C, int mid, const int* N, const int* H, const int* W, int L, hipStream_t stream) {
+    GDT_REQUIRE(L >= 1 && L <= GDT_MAX_LEVELS, "1..4 geometries per launch");
+    if (L == 1) return gdt_launch_bneck(x[0], y[0], wr, w3, we, br, b3, be, wd, bd, cin, C, mid, N[0], H[0], W[0], stream);
+    BneckLaunch dl[GDT_MAX_LEVELS];
+    const int ph = (C == 512) ? 8 : 16;
+    bool ragged = false;
+    for (int l = 0; l < L; ++l) {
+        dl[l] = BneckLaunch{nullptr, x[l], y[l], wr, w3, we, br, b3, be, wd, bd, N[l], H[l], W[l]};
+        ragged = ragged || (H[l] % ph) || (W[l] % PW);
+    }
+    if (cin == 256 && C == 256 && mid == 64 && !wd) return ragged ? launch_multi<256, 64, 16, 256, false, true>(dl, L, stream) : launch_multi<256, 64, 16>(dl, L, stream);
+    if (cin == 512 && C == 512 && mid == 128 && !wd) return ragged ? launch_multi<512, 128, 8, 512, false, true>(dl, L, stream) : launch_multi<512, 128, 8>(dl, L, stream);
+    if (cin == 64 && C == 256 && mid == 64 && wd && bd) return ragged ? launch_multi<256, 64, 16, 64, true, true>(dl, L, stream) : launch_multi<256, 64, 16, 64, true>(dl, L, stream);
+    gdt_set_error("gdt_launch_bneck_levels: unsupported shape");
     return GDT_ERR_INVALID;
 }

@@ -313,6 +313,17 @@ bool gdt_conv_pool2_eligible(const ConvLaunch& d) {
 
 int gdt_conv_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
+// Which kernel family gdt_launch_conv picks for `d` (same order of choice), for the families that can run several geometries in one launch:
+// 1 = conv1x1_rb.hip, 2 = conv3x3_halo_rb.hip, 0 = any other
+int gdt_conv_family(const ConvLaunch& d) {
+    if (d.pool2 || d.stats || d.in_norm) return 0;
+    if (gdt_conv_stem_eligible(d)) return 0;
+    if (gdt_conv_1x1_rb_eligible(d)) return 1;
+    if (!gdt_conv_halo_rb_eligible(d) && !gdt_conv_halo_eligible(d) && gdt_conv_igemm_rb_eligible(d)) return 0;
+    if (gdt_conv_halo_rb_eligible(d)) return 2;
+    return 0;
+}
+
 int gdt_launch_conv(const ConvLaunch& d_in, hipStream_t stream, int* variant) {
     int vdummy; if (!variant) variant = &vdummy;
     static const int dbg = [] { const char* e = getenv("GDT_CONV_DBG"); return e ? atoi(e) : 0; }();

@@ -131,6 +131,47 @@ struct ConvLaunch {
     const f16* r_w_frag; const float* r_bias; f16* r_out;
 };
 
+// ---- several independent geometries in ONE launch (round 5: the levels of a multi-scale pyramid, wrapper.py:221-233 / network.py:139-140) ----
+// Every level keeps its own launch descriptor (its own pointers, N, H, W: the levels need not be contiguous); the workgroups of the grid are dealt out to the
+// levels in contiguous ranges proportional to their tiles (whole multiples of 8, so that the XCD of a workgroup -- blockIdx & 7 -- is what its level's tile walk
+// assumes) and every workgroup runs the unchanged kernel body on its level's descriptor with its index and its level's grid size in place of blockIdx /
+// gridDim.  Results are those of the levels launched one by one with the same kernel instantiation, bit for bit.
+// MEASURED (GeM-ResNet-101, 8 x 1024^2, hub scales; tools/ab_levels.py, alternating inside one process): 82 of the 88 launches the three levels hand in are
+// joined, 120 launches instead of 300 -- and the forward takes 7.44 ms against 7.09 ms with one side stream per level (sms preset 15.9 vs 14.0): the 1x1 convs
+// have thousands of tiles per level, so a joined launch takes the SUM of its levels' times like the streams do, a level has its share of the chip for the
+// whole op instead of what is free at the moment, and the ranges' rounding to XCD rounds adds a tail per op.  The other arrangement -- every workgroup walks
+// the levels' tile lists one after the other with the whole grid -- measured 10.1 ms (the level-by-level sum).  The streams stay the default
+// (GANDTR_HIP_JOINT_LEVELS=1 selects this path).
+constexpr int GDT_MAX_LEVELS = 4;
+struct MultiConv {
+    int nlev;
+    int prefix[GDT_MAX_LEVELS + 1];      // first workgroup of each level; prefix[nlev] = grid size
+    int vblocks[GDT_MAX_LEVELS];         // virtual blocks (tile walk length) of each level
+    ConvLaunch lev[GDT_MAX_LEVELS];
+};
+__device__ __forceinline__ int gdt_multi_level(const int nlev, const int* prefix, const int b) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < GDT_MAX_LEVELS; ++k) l += (k < nlev && b >= prefix[k]) ? 1 : 0;
+    return l;
+}
+// host: grid ranges per level -- every level all its virtual blocks when they fit `slots` together, else shares in proportion (multiples of 8, at least 8)
+inline int gdt_multi_partition(int* prefix, const int* vb, int L, int slots) {
+    long total = 0;
+    for (int l = 0; l < L; ++l) total += vb[l];
+    prefix[0] = 0;
+    for (int l = 0; l < L; ++l) {
+        int g = vb[l];
+        if (total > slots) {
+            g = (int)((long)slots * vb[l] / total) / 8 * 8;
+            if (g < 8) g = 8;
+            if (g > vb[l]) g = vb[l];
+        }
+        prefix[l + 1] = prefix[l] + g;
+    }
+    return prefix[L];
+}
+
 // variant (optional out): which kernel ran -- BM*1000+BN for conv_igemm_kernel<BM,BN,..>, 900000+BN for conv3x3_halo_kernel<BN,..>, 910000+BN for conv3x3_halo_rb_kernel<BN,..>
 // Workgroup -> (M tile, N tile).  Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md), each
 // with a private L2.  Every XCD therefore gets ONE contiguous span of M tiles: spatially adjacent tiles (which share input
@@ -148,6 +189,7 @@ __device__ __forceinline__ bool gdt_tile_of_block(int b, int ntm, int ntn, int& 
 inline int gdt_grid_for_tiles(int ntm, int ntn) { return 8 * ((ntm + 7) / 8) * ntn; }
 
 int gdt_launch_conv(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
+int gdt_conv_family(const ConvLaunch& d);                  // conv_igemm.hip: 1 conv1x1_rb, 2 conv3x3_halo_rb, 0 other (the families with a multi-geometry entry)
 bool gdt_conv_igemm_norm_eligible(const ConvLaunch& d);    // conv_igemm.hip: fused input InstanceNorm in the generic kernel
 bool gdt_conv_halo_eligible(const ConvLaunch& d);          // conv3x3_halo.hip
 int gdt_launch_conv_halo(const ConvLaunch& d, hipStream_t stream);
@@ -156,6 +198,8 @@ bool gdt_conv3x3_expand_eligible(const ConvLaunch& d);     // conv3x3_expand_rb.
 int gdt_launch_conv3x3_expand(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv3x3_expand_chain_eligible(const ConvLaunch& d);   // ... with the next block's reduce conv as a third phase of the same launch (variant 938000 + x_cout / 8)
 int gdt_launch_conv_halo_rb(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_halo_rb_levels_ok(const ConvLaunch* dl, int L);                          // ... the plain form on L independent geometries in one launch (MultiConv)
+int gdt_launch_conv_halo_rb_levels(const ConvLaunch* dl, int L, hipStream_t stream);
 bool gdt_conv_pool2_eligible(const ConvLaunch& d);         // conv_igemm.hip: can this launch (pool2 = 0) take a fused 2x2 max pool?
 bool gdt_conv_halo_ct_eligible(const ConvLaunch& d);       // conv3x3_halo_rb.hip, transposed form (variant 960256)
 int gdt_launch_conv_halo_ct(const ConvLaunch& d, hipStream_t stream);
@@ -167,6 +211,7 @@ int gdt_launch_conv_stem_pair(const ConvLaunch& d, const float* x, int C, const 
 int gdt_launch_conv_stem_pair_pool(const ConvLaunch& d, const float* x, int C, const int* perm, const float* scale, const float* shift, int PH, int PW, hipStream_t stream);   // ... + MaxPool2d(3, 2, 1) (variant 952049)
 bool gdt_conv_1x1_rb_eligible(const ConvLaunch& d);        // conv1x1_rb.hip (streaming 1x1 conv, variant 945128)
 int gdt_launch_conv_1x1_rb(const ConvLaunch& d, hipStream_t stream);
+int gdt_launch_conv_1x1_rb_levels(const ConvLaunch* dl, int L, hipStream_t stream);     // ... on L independent geometries in one launch (MultiConv)
 bool gdt_conv_1x1_cat_eligible(const ConvLaunch& d);       // ... its K-concatenated form (variant 946128)
 // fused transposed conv (phase_cout > 0): GEMM column c -> (sub-pixel phase, output channel).  Each 64-column wave slice pairs
 // a cheap phase with an expensive one -- 32 columns of phase 0 (1 input shift) + 32 of phase 3 (4 shifts), or 1 + 2 (2 + 2) --
@@ -204,4 +249,6 @@ int gdt_launch_conv_halo_c_s2(const ConvLaunch& d, hipStream_t stream);
 bool gdt_bneck_eligible(int cin, int C, int mid, int N, int H, int W);   // conv_bneck.hip: Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut) as one launch (variant 935000 + C)
 int gdt_launch_bneck(const f16* x, f16* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
                      const f16* wd, const float* bd, int cin, int C, int mid, int N, int H, int W, hipStream_t stream);   // wd / bd: 1x1 projection shortcut (cin != C), else null
+int gdt_launch_bneck_levels(const f16* const* x, f16* const* y, const f16* wr, const f16* w3, const f16* we, const float* br, const float* b3, const float* be,
+                            const f16* wd, const float* bd, int cin, int C, int mid, const int* N, const int* H, const int* W, int L, hipStream_t stream);   // ... on L geometries in one launch
 int gdt_conv_bn(int Cout);    // N tile used for a given Cout (CoutPad must be a multiple of it)

@@ -136,6 +136,7 @@ struct gdt_net {
     std::vector<double> last_flops;
     std::vector<double> last_bytes;         // algorithmic HBM bytes per op (op_bytes), merged like last_flops when ops are fused
     std::vector<int> last_variant;          // kernel variant per conv op (see gdt_launch_conv)
+    int last_joined = 0, last_level_launches = 0;   // gdt_net_forward_levels: ops whose levels shared ONE launch / launches handed back by the levels in total
 
     size_t blob_append(const void* data, size_t bytes) {
         const size_t off = align_up(host_blob.size());
@@ -1416,39 +1417,41 @@ int gdt_net_profile_read_bytes(gdt_net* net, int max_ops, int* n_ops, double* by
     return GDT_OK;
 }
 
-int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
-                    void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream) {
-    GDT_REQUIRE(net && net->finalized, "net must be finalized");
-    GDT_REQUIRE(x && n >= 1 && h >= 1 && w >= 1 && rh >= 1 && rw >= 1, "input geometry");
-    GDT_REQUIRE(n_outputs == (int)net->out_ops.size() && (outputs || n_outputs == 0), "output count");
-    GDT_REQUIRE((long)n * rh * rw < (1l << 31) && (long)n * h * w < (1l << 31), "N*H*W must stay below 2^31");
-    for (int i = 0; i < n_outputs; ++i) GDT_REQUIRE(outputs[i] != nullptr, "null output buffer");
-    Plan plan;
-    int rc = make_plan(net, n, rh, rw, plan, rh == h && rw == w);
-    if (rc != GDT_OK) return rc;
-    if (plan.peak + ALIGN > workspace_bytes || !workspace) {
-        gdt_set_error("workspace too small: need " + std::to_string(plan.peak + ALIGN) + " bytes, got " + std::to_string(workspace_bytes));
-        return GDT_ERR_WORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
-    auto& T = net->tensors;
+}  // extern "C"
+
+namespace {
+
+// one geometry of a forward: its input, outputs, workspace and the plan made for it (a snapshot of the planned tensor table: make_plan works on net->tensors)
+struct LevelCtx {
+    const float* x; int n, h, w, rh, rw; float rscale;
+    void* const* outputs; char* ws;
+    Plan plan; std::vector<Tensor> T;
+};
+enum { DEFER_NONE = 0, DEFER_CONV = 1, DEFER_BNECK = 2 };
+// a launch a step WOULD make, handed back instead of issued: the lock-step driver (several geometries per forward) joins the levels' launches of one op
+struct Deferred {
+    int kind = DEFER_NONE;
+    bool kcat = false;
+    ConvLaunch d;                                // DEFER_CONV: the descriptor gdt_launch_conv / gdt_launch_conv_1x1_rb (kcat) would get
+    const f16* bx = nullptr; f16* by = nullptr; int bn = 0, bh = 0, bw = 0;      // DEFER_BNECK: block input / output and geometry (the weights are the op's)
+};
+
+// One op of the graph on one geometry.  `defer` != null: launches that can share a launch with the other geometries' are handed back (kind != DEFER_NONE) instead
+// of issued.  `book`: per-op profile bookkeeping of fused launches (once per forward).
+int exec_step(gdt_net* net, LevelCtx& c, const Step& stp, hipStream_t st, Deferred* defer, bool book) {
+    const int n = c.n, h = c.h, w = c.w, rh = c.rh, rw = c.rw;
+    const float rscale = c.rscale;
+    const float* x = c.x;
+    void* const* outputs = c.outputs;
+    char* ws = c.ws;
+    auto& T = c.T;
+    const Plan& plan = c.plan;
     auto tptr = [&](int t) { return (f16*)(ws + T[t].off); };      // element type is fp16 or fp32 (net->precision)
     const int f32 = net->precision ? 1 : 0;      // activation element type handed to the helper kernels: fp32 in both split modes
     const f16* zeros = (const f16*)(net->dev_blob + net->zeros_off);
-
-    if (net->profiling) {
-        net->last_flops.resize(net->ops.size());
-        net->last_variant.assign(net->ops.size(), 0);
-        net->last_bytes.resize(net->ops.size());
-        for (size_t i = 0; i < net->ops.size(); ++i) {
-            net->last_flops[i] = op_flops(net, net->ops[i], n, rh, rw);
-            net->last_bytes[i] = op_bytes(net, net->ops[i], n);
-        }
-    }
-    for (const Step& stp : plan.steps) {
-        const Op& o = net->ops[stp.op];
-        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * stp.op], st));
+    const Op& o = net->ops[stp.op];
+    int rc = GDT_OK;
+    (void)h; (void)w; (void)rscale; (void)x;
         switch (o.kind) {
             case OP_INPUT: {
                 const int resize = (rh != h || rw != w) ? 1 : 0;
@@ -1463,13 +1466,15 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     const bool dsf = stp.bneck_ds >= 0;
                     const Op &oa = net->ops[stp.bneck_a], &ob = net->ops[stp.op + (dsf ? 2 : 1)], &oc = net->ops[stp.op + (dsf ? 3 : 2)];
                     const Op* od = dsf ? &net->ops[stp.bneck_ds] : nullptr;
+                    if (defer) { defer->kind = DEFER_BNECK; defer->bx = tptr(oa.in); defer->by = tptr(oc.out); defer->bn = n; defer->bh = T[oa.in].H; defer->bw = T[oa.in].W; }
+                    else
                     rc = gdt_launch_bneck(tptr(oa.in), tptr(oc.out), (const f16*)(net->dev_blob + oa.phases[0].w_frag_off),
                                           (const f16*)(net->dev_blob + ob.phases[0].w_frag_off), (const f16*)(net->dev_blob + oc.phases[0].w_frag_off),
                                           (const float*)(net->dev_blob + oa.bias_off), (const float*)(net->dev_blob + ob.bias_off),
                                           (const float*)(net->dev_blob + oc.bias_off),
                                           od ? (const f16*)(net->dev_blob + od->phases[0].w_frag_off) : nullptr, od ? (const float*)(net->dev_blob + od->bias_off) : nullptr,
                                           oa.cd.cin, oc.cd.cout, oa.cd.cout, n, T[oa.in].H, T[oa.in].W, st);
-                    if (net->profiling) {      // the block's FLOPs and time are booked on its first conv
+                    if (net->profiling && book) {      // the block's FLOPs and time are booked on its first conv
                         net->last_variant[stp.op] = 935000 + oc.cd.cout + (dsf ? 1 : 0);
                         for (int k = 1; k <= (dsf ? 3 : 2); ++k) { net->last_flops[stp.op] += net->last_flops[stp.op + k]; net->last_flops[stp.op + k] = 0.0; }
                         // bytes: the block-boundary tensors (x once -- it is also the residual --, y once) and every weight matrix once
@@ -1518,7 +1523,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                         d.r_out = tptr(a2.out);
                     }
                     rc = gdt_launch_conv3x3_expand(d, st);
-                    if (net->profiling) {
+                    if (net->profiling && book) {
                         net->last_variant[stp.op] = (stp.xchain >= 0 ? 938000 : 939000) + oc.cd.cout / 8;
                         net->last_flops[stp.op] += net->last_flops[stp.op + 1]; net->last_flops[stp.op + 1] = 0.0;
                         // bytes: the 256-channel tensor between the two convs is neither written nor read
@@ -1542,8 +1547,9 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     d.bias = (const float*)(net->dev_blob + o.kcat_bias_off);
                     d.Kpad = o.cin_pad + ds.cin_pad; d.nk = d.Kpad / 64;
                     d.in2 = tptr(ds.in); d.in2_cin = ds.cin_pad; d.in2_h = T[ds.in].H; d.in2_w = T[ds.in].W; d.in2_stride = ds.cd.stride;
-                    rc = gdt_launch_conv_1x1_rb(d, st);
-                    if (net->profiling) {
+                    if (defer) { defer->kind = DEFER_CONV; defer->kcat = true; defer->d = d; }
+                    else rc = gdt_launch_conv_1x1_rb(d, st);
+                    if (net->profiling && book) {
                         net->last_variant[stp.op] = 946128;
                         net->last_flops[stp.op] += net->last_flops[o.kcat_ds]; net->last_flops[o.kcat_ds] = 0.0;
                         // bytes: the projected tensor is neither written (projection op) nor read back as the residual (expand op)
@@ -1633,6 +1639,7 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                     if (stp.aug) { d.w_frag2 = (const f16*)(net->dev_blob + ph.w_frag2_off); variant = 955000 + ph.ntaps; rc = gdt_launch_conv_stem_c(d, st); }
                     else if (net->precision == 2 && gdt_conv_halo_c16_eligible(d)) { variant = 971256; rc = gdt_launch_conv_halo_c16(d, st); }
                     else if (net->precision == 2 && gdt_conv_halo_c_eligible(d)) { variant = 970000 + gdt_conv_halo_c_columns(d); rc = gdt_launch_conv_halo_c(d, st); }
+                    else if (defer && !f32 && o.phases.size() == 1 && !o.rowsplit && !o.cd.out_f32_nchw) { defer->kind = DEFER_CONV; defer->kcat = false; defer->d = d; }
                     else rc = f32 ? gdt_launch_conv_x3(d, st, &variant) : gdt_launch_conv(d, st, &variant);
                     if (net->profiling) net->last_variant[stp.op] = variant;
                     if (rc != GDT_OK) break;
@@ -1690,10 +1697,143 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
                 break;
             }
         }
+    return rc;
+}
+
+// weights of a fused Bottleneck step (the same for every geometry)
+int launch_bneck_levels(gdt_net* net, const Step& stp, const Deferred* df, int L, hipStream_t st) {
+    const bool dsf = stp.bneck_ds >= 0;
+    const Op &oa = net->ops[stp.bneck_a], &ob = net->ops[stp.op + (dsf ? 2 : 1)], &oc = net->ops[stp.op + (dsf ? 3 : 2)];
+    const Op* od = dsf ? &net->ops[stp.bneck_ds] : nullptr;
+    const f16* xs[GDT_MAX_LEVELS]; f16* ys[GDT_MAX_LEVELS]; int ns[GDT_MAX_LEVELS], hs[GDT_MAX_LEVELS], wsz[GDT_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) { xs[l] = df[l].bx; ys[l] = df[l].by; ns[l] = df[l].bn; hs[l] = df[l].bh; wsz[l] = df[l].bw; }
+    return gdt_launch_bneck_levels(xs, ys, (const f16*)(net->dev_blob + oa.phases[0].w_frag_off), (const f16*)(net->dev_blob + ob.phases[0].w_frag_off),
+                                   (const f16*)(net->dev_blob + oc.phases[0].w_frag_off), (const float*)(net->dev_blob + oa.bias_off),
+                                   (const float*)(net->dev_blob + ob.bias_off), (const float*)(net->dev_blob + oc.bias_off),
+                                   od ? (const f16*)(net->dev_blob + od->phases[0].w_frag_off) : nullptr, od ? (const float*)(net->dev_blob + od->bias_off) : nullptr,
+                                   oa.cd.cin, oc.cd.cout, oa.cd.cout, ns, hs, wsz, L, st);
+}
+
+// The forward on L independent geometries in lock-step: op by op, every geometry's launch of the op -- joined into ONE launch where the kernel has a
+// multi-geometry entry and the levels select the same kernel family (conv1x1_rb.hip, conv3x3_halo_rb.hip, conv_bneck.hip), else issued one after the other
+int forward_levels(gdt_net* net, LevelCtx* cx, int L, hipStream_t st) {
+    const int nops = (int)net->ops.size();
+    net->last_joined = 0; net->last_level_launches = 0;
+    if (net->profiling) {
+        net->last_flops.assign(nops, 0.0);
+        net->last_variant.assign(nops, 0);
+        net->last_bytes.assign(nops, 0.0);
+        for (int l = 0; l < L; ++l) {
+            net->tensors = cx[l].T;                    // (op_flops / op_bytes read the planned shapes from the net's table)
+            for (int i = 0; i < nops; ++i) {
+                net->last_flops[i] += op_flops(net, net->ops[i], cx[l].n, cx[l].rh, cx[l].rw);
+                net->last_bytes[i] += op_bytes(net, net->ops[i], cx[l].n);
+            }
+        }
+    }
+    for (int i = 0; i < nops; ++i) {
+        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * i], st));
+        int rc = GDT_OK;
+        if (L == 1) rc = exec_step(net, cx[0], cx[0].plan.steps[i], st, nullptr, true);
+        else {
+            Deferred df[GDT_MAX_LEVELS];
+            int nconv = 0, nbneck = 0, nkcat = 0;
+            for (int l = 0; l < L && rc == GDT_OK; ++l) {
+                rc = exec_step(net, cx[l], cx[l].plan.steps[i], st, &df[l], l == 0);
+                nconv += df[l].kind == DEFER_CONV; nbneck += df[l].kind == DEFER_BNECK; nkcat += df[l].kind == DEFER_CONV && df[l].kcat;
+            }
+            if (rc != GDT_OK) return rc;
+            net->last_level_launches += nconv + nbneck;
+            bool joined = false;
+            if (nbneck == L) { rc = launch_bneck_levels(net, cx[0].plan.steps[i], df, L, st); joined = true; }
+            else if (nconv == L && (nkcat == 0 || nkcat == L)) {
+                ConvLaunch dl[GDT_MAX_LEVELS];
+                int fam = nkcat ? 1 : gdt_conv_family(df[0].d);
+                for (int l = 0; l < L; ++l) { dl[l] = df[l].d; if (!nkcat && gdt_conv_family(df[l].d) != fam) fam = 0; }
+                if (fam == 1) { rc = gdt_launch_conv_1x1_rb_levels(dl, L, st); joined = true; if (net->profiling && !nkcat) net->last_variant[i] = 945128; }
+                else if (fam == 2 && gdt_conv_halo_rb_levels_ok(dl, L)) { rc = gdt_launch_conv_halo_rb_levels(dl, L, st); joined = true; if (net->profiling) net->last_variant[i] = 910256; }
+            }
+            if (joined) ++net->last_joined;
+            static const bool lv_dbg = getenv("GDT_LEVELS_DEBUG") != nullptr;
+            if (lv_dbg && (nconv || nbneck)) {
+                fprintf(stderr, "[levels] op %d joined %d:", i, (int)joined);
+                for (int l = 0; l < L; ++l) {
+                    if (df[l].kind == DEFER_CONV) fprintf(stderr, " [conv%s fam %d M %d Cin %d Cout %d taps %d s%d]", df[l].kcat ? " kcat" : "", gdt_conv_family(df[l].d), df[l].d.M, df[l].d.Cin, df[l].d.Cout, df[l].d.ntaps, df[l].d.sy);
+                    else if (df[l].kind == DEFER_BNECK) fprintf(stderr, " [bneck %dx%dx%d]", df[l].bn, df[l].bh, df[l].bw);
+                    else fprintf(stderr, " [-]");
+                }
+                fprintf(stderr, "\n");
+            }
+            if (!joined) {                    // one by one (levels whose step was not handed back have launched already)
+                for (int l = 0; l < L && rc == GDT_OK; ++l) {
+                    if (df[l].kind == DEFER_BNECK) rc = launch_bneck_levels(net, cx[l].plan.steps[i], &df[l], 1, st);
+                    else if (df[l].kind == DEFER_CONV && df[l].kcat) rc = gdt_launch_conv_1x1_rb(df[l].d, st);
+                    else if (df[l].kind == DEFER_CONV) { int variant = 0; rc = gdt_launch_conv(df[l].d, st, &variant); if (net->profiling && l == 0) net->last_variant[i] = variant; }
+                }
+            }
+        }
         if (rc != GDT_OK) return rc;
-        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * stp.op + 1], st));
+        if (net->profiling) GDT_CHECK_HIP(hipEventRecord(net->events[2 * i + 1], st));
     }
     return GDT_OK;
+}
+
+int plan_level(gdt_net* net, LevelCtx& c, void* workspace, size_t workspace_bytes) {
+    int rc = make_plan(net, c.n, c.rh, c.rw, c.plan, c.rh == c.h && c.rw == c.w);
+    if (rc != GDT_OK) return rc;
+    if (c.plan.peak + ALIGN > workspace_bytes || !workspace) {
+        gdt_set_error("workspace too small: need " + std::to_string(c.plan.peak + ALIGN) + " bytes, got " + std::to_string(workspace_bytes));
+        return GDT_ERR_WORKSPACE;
+    }
+    c.ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
+    c.T = net->tensors;
+    return GDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
+                    void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream) {
+    GDT_REQUIRE(net && net->finalized, "net must be finalized");
+    GDT_REQUIRE(x && n >= 1 && h >= 1 && w >= 1 && rh >= 1 && rw >= 1, "input geometry");
+    GDT_REQUIRE(n_outputs == (int)net->out_ops.size() && (outputs || n_outputs == 0), "output count");
+    GDT_REQUIRE((long)n * rh * rw < (1l << 31) && (long)n * h * w < (1l << 31), "N*H*W must stay below 2^31");
+    for (int i = 0; i < n_outputs; ++i) GDT_REQUIRE(outputs[i] != nullptr, "null output buffer");
+    LevelCtx c;
+    c.x = x; c.n = n; c.h = h; c.w = w; c.rh = rh; c.rw = rw; c.rscale = rscale; c.outputs = outputs;
+    int rc = plan_level(net, c, workspace, workspace_bytes);
+    if (rc != GDT_OK) return rc;
+    return forward_levels(net, &c, 1, (hipStream_t)stream);
+}
+
+int gdt_net_levels_joined(gdt_net* net, int* level_launches) {
+    if (!net) return 0;
+    if (level_launches) *level_launches = net->last_level_launches;
+    return net->last_joined;
+}
+
+int gdt_net_forward_levels(gdt_net* net, const gdt_level* levels, int n_levels, void* stream) {
+    GDT_REQUIRE(net && net->finalized, "net must be finalized");
+    GDT_REQUIRE(levels && n_levels >= 1 && n_levels <= GDT_MAX_LEVELS, "1..4 geometries per call");
+    std::vector<LevelCtx> cx(n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        const gdt_level& g = levels[l];
+        GDT_REQUIRE(g.x && g.n >= 1 && g.h >= 1 && g.w >= 1 && g.rh >= 1 && g.rw >= 1, "input geometry");
+        GDT_REQUIRE(g.n_outputs == (int)net->out_ops.size() && (g.outputs || g.n_outputs == 0), "output count");
+        GDT_REQUIRE((long)g.n * g.rh * g.rw < (1l << 31) && (long)g.n * g.h * g.w < (1l << 31), "N*H*W must stay below 2^31");
+        for (int i = 0; i < g.n_outputs; ++i) GDT_REQUIRE(g.outputs[i] != nullptr, "null output buffer");
+        for (int k = 0; k < l; ++k) {      // every geometry its own scratch memory
+            const char *a0 = (const char*)levels[k].workspace, *a1 = a0 + levels[k].workspace_bytes, *b0 = (const char*)g.workspace, *b1 = b0 + g.workspace_bytes;
+            GDT_REQUIRE(a1 <= b0 || b1 <= a0, "the geometries of one call need disjoint workspaces");
+        }
+        LevelCtx& c = cx[l];
+        c.x = g.x; c.n = g.n; c.h = g.h; c.w = g.w; c.rh = g.rh; c.rw = g.rw; c.rscale = g.rscale; c.outputs = g.outputs;
+        const int rc = plan_level(net, c, g.workspace, g.workspace_bytes);
+        if (rc != GDT_OK) return rc;
+    }
+    return forward_levels(net, cx.data(), n_levels, (hipStream_t)stream);
 }
 
 int gdt_ms_aggregate(const float* x, float* y, int scales, int n, int d, float msp, void* stream) {

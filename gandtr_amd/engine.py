@@ -240,7 +240,11 @@ class HipNet:
         ``side_workspace_cap`` bytes in total (default 8 GiB); beyond it they are released when the call returns."""
         if not self._finalized:
             raise RuntimeError("HipNet.forward_many before finalize()")
-        if len(inputs) == 1 or getattr(self, "_profiling", False) or os.environ.get("GANDTR_HIP_CONCURRENT_LEVELS", "1") == "0":
+        if len(inputs) == 1 or os.environ.get("GANDTR_HIP_CONCURRENT_LEVELS", "1") == "0":
+            return [self.forward(x, scale=s) for x, s in inputs]
+        if os.environ.get("GANDTR_HIP_JOINT_LEVELS", "0") == "1":           # (opt-in: measured 5-12 % slower than the side streams, csrc/gdt_common.h MultiConv)
+            return self._forward_levels(inputs)
+        if getattr(self, "_profiling", False):
             return [self.forward(x, scale=s) for x, s in inputs]
         dev = self.device
         cur = torch.cuda.current_stream(dev)
@@ -273,6 +277,61 @@ class HipNet:
                 cur.wait_stream(pools["streams"][k])
                 for o in results[k]:
                     o.record_stream(cur)
+            held = sum(w.numel() for w in pools["ws"] if w is not None)
+            if held > getattr(self, "side_workspace_cap", 8 << 30):
+                for k, w in enumerate(pools["ws"]):
+                    if w is not None:
+                        w.record_stream(cur)
+                        pools["ws"][k] = None
+        return results
+
+    MAX_LEVELS = 4          # GDT_MAX_LEVELS (csrc/gdt_common.h): geometries per gdt_net_forward_levels call
+
+    def levels_joined(self):
+        """(ops whose levels shared one launch, launches the levels handed to the lock-step driver) of the last forward_many group"""
+        n = ctypes.c_int()
+        j = int(self.lib.gdt_net_levels_joined(self.handle, ctypes.byref(n)))
+        return j, n.value
+
+    def _forward_levels(self, inputs):
+        """``inputs`` in groups of at most four geometries, each group ONE ``gdt_net_forward_levels`` call on the caller's stream: the ops run in lock-step and the
+        levels' launches of an op are one launch wherever the kernel has a multi-geometry entry (1x1 convs, 3x3 patch convs, fused Bottlenecks; round 5).  OPT-IN
+        (GANDTR_HIP_JOINT_LEVELS=1): 120 launches instead of 300 for a three-level ResNet-101 pyramid, but 5-12 % slower than one side stream per level
+        (csrc/gdt_common.h, MultiConv: measurements).  Every level has its own scratch buffer (kept between calls up to ``side_workspace_cap`` bytes in total); results are those of
+        ``forward`` level by level, bit for bit (tests/test_hip_f16c.py::test_forward_many_equals_level_by_level_forward)."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        pools = self.__dict__.setdefault("_side", {"streams": [], "ws": []})
+        while len(pools["ws"]) < min(len(inputs), self.MAX_LEVELS):
+            pools["streams"].append(torch.cuda.Stream(device=dev))
+            pools["ws"].append(None)
+        results = []
+        with torch.cuda.device(dev):
+            for lo in range(0, len(inputs), self.MAX_LEVELS):
+                group = inputs[lo:lo + self.MAX_LEVELS]
+                levels = (_hip.Level * len(group))()
+                keep = []
+                for k, (x, scale) in enumerate(group):
+                    if x.dim() != 4 or x.shape[1] != self.in_channels:
+                        raise ValueError("expected an N x %s x H x W input, got %s" % (self.in_channels, tuple(x.shape)))
+                    x = x.to(dev).contiguous().float()
+                    n, _, h, w = x.shape
+                    rh, rw = self.resized_size(h, w, scale)
+                    need = self.workspace_bytes(n, rh, rw)
+                    if pools["ws"][k] is None or pools["ws"][k].numel() < need:
+                        pools["ws"][k] = None
+                        pools["ws"][k] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    outs = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in self.output_shapes(n, rh, rw)]
+                    optrs = (ctypes.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
+                    lv = levels[k]
+                    lv.x, lv.n, lv.h, lv.w, lv.rh, lv.rw = x.data_ptr(), n, h, w, rh, rw
+                    lv.rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
+                    lv.outputs, lv.n_outputs = optrs, len(outs)
+                    lv.workspace, lv.workspace_bytes = pools["ws"][k].data_ptr(), pools["ws"][k].numel()
+                    keep.append((x, optrs))
+                    results.append(outs)
+                _hip.check(self.lib.gdt_net_forward_levels(self.handle, levels, len(group), cur.cuda_stream))
+                del keep
             held = sum(w.numel() for w in pools["ws"] if w is not None)
             if held > getattr(self, "side_workspace_cap", 8 << 30):
                 for k, w in enumerate(pools["ws"]):

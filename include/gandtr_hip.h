@@ -125,6 +125,21 @@ int gdt_net_workspace_bytes(gdt_net* net, int n, int rh, int rw, size_t* bytes);
 int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, int rw, float rscale,
                     void* const* outputs, int n_outputs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The forward on several independent geometries at once -- the levels of a multi-scale pyramid (CirMultiscaleAggregation.preprocess, mdir/components/data/wrapper.py:221-233,
+ * whose levels the reference runs one after the other, mdir/learning/network.py:139-140), or equal-shaped groups of a list of images.  Every level has its own input,
+ * (resized) size, outputs and DISJOINT workspace (sized by gdt_net_workspace_bytes for its geometry).  The ops run in lock-step; where the kernel has a
+ * multi-geometry entry (1x1 convs, 3x3 patch convs, fused Bottlenecks) the levels' launches of an op are ONE launch, whose workgroups are dealt out to the levels.
+ * Results are those of gdt_net_forward called level by level, bit for bit. */
+typedef struct gdt_level {
+    const float* x; int n, h, w, rh, rw; float rscale;      /* as the arguments of gdt_net_forward */
+    void* const* outputs; int n_outputs;
+    void* workspace; size_t workspace_bytes;
+} gdt_level;
+int gdt_net_forward_levels(gdt_net* net, const gdt_level* levels, int n_levels, void* stream);
+/* diagnostics of the last gdt_net_forward_levels call: returns the number of ops whose levels ran as ONE launch; *level_launches = launches the levels handed
+ * to the lock-step driver in total (joined or not) */
+int gdt_net_levels_joined(gdt_net* net, int* level_launches);
+
 /* Algorithmic conv FLOPs (2*MACs, real channel counts, bias/norm/activation excluded) of one forward at this geometry:
  * the numerator of bench.py's roofline.achieved. */
 int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);

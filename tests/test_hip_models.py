@@ -321,6 +321,36 @@ def test_forward_many_equals_level_by_level_forward(cuda_device):
         assert all(torch.equal(a, b) for a, b in zip(w, g))
 
 
+def test_pyramid_levels_share_launches_bitwise(cuda_device):
+    """Round 5: the levels of a pyramid in lock-step, ONE launch per op across the levels where the kernel has a multi-geometry entry (gdt_net_forward_levels:
+    1x1 convs, 3x3 patch convs, fused Bottlenecks) -- at BASELINE config 4's per-rank geometry scaled down (8 images, hub-default scales {1, 1/sqrt2, 1/2},
+    wrapper.py:207-208).  Same bits as forward called level by level, and as the default path (one side stream per level).  Opt-in (GANDTR_HIP_JOINT_LEVELS=1):
+    measured slower than the streams (csrc/gdt_common.h, MultiConv)."""
+    import os
+    from gandtr_amd import engine
+    for arch, sd, size in (("resnet101", synth.resnet101_state(0), 512), ("vgg16", synth.vgg16_state(0), 384)):
+        net = engine.build_embedder(sd, cuda_device)
+        x = synth.synth_input(91, (8, 3, size, size)).to(cuda_device)
+        levels = [(x, 1.0), (x, 2 ** -0.5), (x, 0.5)]
+        want = [[o.clone() for o in net.forward(xx, scale=s)] for xx, s in levels]
+        os.environ["GANDTR_HIP_JOINT_LEVELS"] = "1"
+        try:
+            got = net.forward_many(levels)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["GANDTR_HIP_JOINT_LEVELS"]
+        joined, handed = net.levels_joined()
+        print("%s 8 x %d^2, 3 levels: %d ops ran as one launch for all levels (%d launches handed in by the levels)" % (arch, size, joined, handed))
+        for w, g in zip(want, got):
+            assert len(w) == len(g) and all(torch.equal(a, b) for a, b in zip(w, g))
+        assert joined >= 20, (joined, handed)                              # (at 8 x 1024^2: 82 of 88; the small levels of this test pick other kernel families)
+        got2 = net.forward_many(levels)                                     # the default: one side stream per level
+        torch.cuda.synchronize()
+        for w, g in zip(want, got2):
+            assert all(torch.equal(a, b) for a, b in zip(w, g))
+        del net
+
+
 def test_hipgraph_replay_equals_eager_launches(cuda_device):
     """opt-in hipGraph replay of whole forwards (GANDTR_HIP_GRAPHS=1 / HipNet.use_graphs): from the second call of a geometry on the forward is captured once and
     replayed -- same kernels, same results bit for bit, for the generator (f16c) and the embedder; another geometry falls back to eager launches"""
