@@ -174,7 +174,7 @@ def pmc_traffic(kernel, key):
         with open(os.path.join(ROOT, "profiles", key)) as f:
             doc = json.load(f)
         # (the profiler names conv3x3_expand_rb_kernel by its patch-height template argument, bench.py by the expand conv's channel count)
-        alias = {"conv3x3_expand_rb_kernel<1024>": "conv3x3_expand_rb_kernel<8>", "conv3x3_expand_rb_kernel<1024>[+next reduce]": "conv3x3_expand_rb_kernel<8, true>"}
+        alias = {"conv3x3_expand_rb_kernel<1024>": "conv3x3_expand_rb_kernel<8>", "conv3x3_expand_rb_kernel<1024>[+next reduce]": "conv3x3_expand_rb_kernel<8>[+next reduce]"}
         ks = doc["kernels"]
         return (ks[kernel] if kernel in ks else ks[alias[kernel]])["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
@@ -419,7 +419,7 @@ def main():
             print("mfma-only measurement failed: %r" % (exc,), file=sys.stderr)
     gen_ips = a.gen_batch * world * a.steps / dt
     gen_ms = dt / a.steps * 1e3
-    roof = conv_roofline(gen, xg, traffic_key="r04_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
+    roof = conv_roofline(gen, xg, traffic_key="r05_pmc_traffic.json" if a.gen_batch == 64 else None) if rank == 0 else None
     if roof is not None:
         # the kernel issues 1.5 MFMA-slots per algorithmic fp16 one (1 fp16 + 1/2 block-scaled): its matrix pipe work is 1.5 x `achieved`
         roof["mfma_work_factor"] = 1.5
@@ -486,7 +486,7 @@ def main():
         dt2 = timed(step, a.steps, a.warmup, dev, distributed)
         r_dps = n_total * a.steps / dt2
         hip_desc0 = emb.forward(xe)[emb.out_slot][0].float().cpu() if want_parity else None
-        roof2 = conv_roofline(emb, xe, traffic_key="r04_pmc_traffic_r101.json" if a.r101_batch == 32 else None) if rank == 0 else None
+        roof2 = conv_roofline(emb, xe, traffic_key="r05_pmc_traffic_r101.json" if a.r101_batch == 32 else None) if rank == 0 else None
         if roof2 is not None and roof2.get("kernel", "").startswith("conv3x3_expand"):
             # the dominant launch is half MFMA-bound (3x3), half HBM-bound (expand + residual + store): both views of the same launches
             roof2["hbm_view"] = {"bound": "hbm", "achieved": round(roof2["algorithmic_bytes_per_launch"] / (roof2["avg_launch_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0,

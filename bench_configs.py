@@ -180,6 +180,23 @@ def self_launch(argv, gpus):
     return subprocess.run(cmd, env=env, check=False).returncode
 
 
+def _cpu_baseline(fn, units, unit, sample, seconds=8.0):
+    """The CPU oracle (oracle/gandtr_oracle.py: the reference's torch ops restated) timed on a bounded sample of the config's workload, on the threads bench.py
+    uses (the cores of this process, at most 16), for about `seconds`: {"value", "unit", "cores", "kind": "port", "sample"}"""
+    import bench
+    cores = bench.host_cores()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            n += units
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%s: %d in %.1f s, torch CPU fp32 oracle, %d threads" % (sample, n, dt, cores)}
+
+
 def _roofline_of(model, x):
     """bench.py's live per-kernel roofline object (HIP events around every op inside the library) for the engine net a hub model has built for its last forward"""
     import bench
@@ -191,7 +208,7 @@ def _roofline_of(model, x):
     return bench.conv_roofline(nets[0], x, steps=2)
 
 
-def main():
+def main(args):
     dev = torch.device("cuda:0")
     out = {}
     with torch.no_grad():
@@ -210,6 +227,10 @@ def main():
         r, ms = rate(lambda: net(x), 32, steps=4, warmup=1)
         out["c1_gem_vgg16_32x1024"] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * 641.4 / 1e3, 1),
                                        "roofline": _roofline_of(net.model, x)}
+        if not args.no_cpu_baseline:
+            from oracle import gandtr_oracle as O
+            sdv, xc = synth.vgg16_state(0), synth.synth_input(2, (1, 3, 1024, 1024))
+            out["c1_gem_vgg16_32x1024"]["cpu_baseline"] = _cpu_baseline(lambda: O.image_retrieval_forward(xc, sdv, "vgg16"), 1, "descriptors/s", "1x3x1024x1024 images")
         del net, x
         torch.cuda.empty_cache()
 
@@ -236,7 +257,13 @@ def main():
         # regression guard (round 1 saw this leg at 4.2 -> 6.5 ms with no kernel change; root cause in DESIGN.md section 6): the HED leg
         # (40.1 GFLOP / image, wrappers folded into its input pack) must stay under 4.5 ms per 64-image batch
         out["c2_hedngan_plus_hed_64x256"]["hed_leg_within_4p5_ms"] = bool(msh < 4.5)
-        out["c2_hedngan_plus_hed_64x256"]["roofline_generator"] = _roofline_of(gen.model, x)
+        out["c2_hedngan_plus_hed_64x256"]["roofline"] = _roofline_of(gen.model, x)          # (the generator leg: 99.1 of the 139.2 GFLOP per image)
+        out["c2_hedngan_plus_hed_64x256"]["roofline_hed_leg"] = _roofline_of(hed.model, gen(x))
+        if not args.no_cpu_baseline:
+            from oracle import gandtr_oracle as O
+            sdg, sdh, xc = synth.generator_state(0, "batch"), synth.hed_state(0), synth.synth_input(3, (4, 3, 256, 256), 1.0)
+            out["c2_hedngan_plus_hed_64x256"]["cpu_baseline"] = _cpu_baseline(
+                lambda: O.hed_on_generator_output(O.resnet_generator(xc, sdg, "batch", 9), sdh), 4, "images/s", "4x3x256x256 batches (BatchNorm generator + HED)")
         del y
         del gen, hed, x
         torch.cuda.empty_cache()
@@ -258,7 +285,16 @@ def main():
             net = N.initialize_network(None, dev, Checkpoints.load_network(os.path.join(tmp, "r101.pth")), runtime).eval()
             r, ms = rate(lambda: net(x), 8, steps=4, warmup=1)
             gf = 574.8 if scales is True else 1151.9
-            out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1)}
+            out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1),
+                                                          "roofline": _roofline_of(net.model, x),      # (the full-size level of the pyramid, 8 x 1024^2)
+                                                          "roofline_note": "per-kernel figures of the scale-1 level alone (8 x 3 x 1024 x 1024); the three levels run concurrently on side streams"}
+            if not args.no_cpu_baseline:
+                from oracle import gandtr_oracle as O
+                sdr, lw, xc = synth.resnet101_state(0), synth.whitening_state(0, 2048), synth.synth_input(4, (1, 3, 1024, 1024))
+                Pm = (torch.from_numpy(lw["P"]), torch.from_numpy(lw["m"]))
+                sc = O.SCALE_PRESETS[scales]
+                out["c3_gem_resnet101_ms_%s_8x1024" % tag]["cpu_baseline"] = _cpu_baseline(
+                    lambda: O.embed_ms_whiten(xc, sdr, "resnet101", sc, Pm[0], Pm[1]), 1, "descriptors/s", "1x3x1024x1024 images, %d-level pyramid + whitening" % len(sc), seconds=6.0)
             if scales is True:                      # the same network on a batch of 32 (what a rank holds when the global batch is 256): the large-geometry kernels apply
                 x32 = synth.synth_input(5, (32, 3, 1024, 1024)).to(dev)
                 r32, ms32 = rate(lambda: net(x32), 32, steps=4, warmup=1)
@@ -305,7 +341,15 @@ def main():
         rf, msf = rate(lambda: chain(x), 128)
         chain.networks["augment"].model.hip_precision = None
         out["c4_augment_then_embed_128x256"] = {"images_per_s": r, "ms_per_batch": ms, "tflops": round(r * 119.5 / 1e3, 1),
-                                                "fast_mode_f16_generator": {"images_per_s": rf, "ms_per_batch": msf}}
+                                                "fast_mode_f16_generator": {"images_per_s": rf, "ms_per_batch": msf},
+                                                "roofline": _roofline_of(chain.networks["augment"].model, x)}       # (the generator leg: 99.1 of the 119.5 GFLOP per image)
+        if not args.no_cpu_baseline:
+            from oracle import gandtr_oracle as O
+            sdg, sdr, xc = synth.generator_state(0, "instance"), synth.resnet101_state(0), synth.synth_input(5, (4, 3, 256, 256), 1.0)
+            ms_gen, ms_emb = [[0.5] * 3, [0.5] * 3], [[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]]
+            out["c4_augment_then_embed_128x256"]["cpu_baseline"] = _cpu_baseline(
+                lambda: O.image_retrieval_forward(O.meanstd_adapt(O.resnet_generator(xc, sdg, "instance", 9), ms_gen, ms_emb), sdr, "resnet101"), 4, "images/s",
+                "4x3x256x256 batches (generator -> meanstd_post -> GeM-ResNet-101)")
         # the same chain with the reference's CLAHE step between generator and embedder (finetune.yml:13: wrappers
         # meanstd_post, clahepost -- post-processing runs in reverse order: CLAHE first, then the ImageNet mean / std)
         gen_c["runtime"]["wrappers"] += ",clahepost:[[0.5,0.5,0.5],[0.5,0.5,0.5]]:1.0"
@@ -378,6 +422,7 @@ if __name__ == "__main__":
     ap.add_argument("--global-batch", type=int, default=0, help="sharded configs: images in the global batch (default: 8 / 128 per rank; any N, the ranks need not divide it)")
     ap.add_argument("--small", action="store_true", help="sharded configs on the GPU with small images (2 x 256^2 / 8 x 64^2 per rank): the RCCL path's functional test")
     ap.add_argument("--check", action="store_true", help="sharded configs: every rank compares the gathered D x N matrix with the single-process result over the same chunks, bit for bit")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (about 8 s each) of the config lines")
     ap.add_argument("--sharded", action="store_true", help="run the sharded configs 4 / 5 even with --gpus 1 (one rank: the same code path, RCCL world size 1)")
     a = ap.parse_args()
     if "RANK" in os.environ and (a.gpus > 1 or a.dry_run or a.sharded):
@@ -385,4 +430,4 @@ if __name__ == "__main__":
     elif a.gpus > 1 or a.dry_run or a.sharded:
         sys.exit(self_launch(sys.argv[1:], max(1, a.gpus)))
     else:
-        main()
+        main(a)

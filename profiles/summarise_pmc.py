@@ -14,7 +14,7 @@ import sys
 
 def short(name):
     """kernel key as bench.py's kernel_name(): template kernels keep their tile arguments"""
-    m = re.search(r"(conv1x1_rb_kernel|conv3x3_expand_rb_kernel|conv_bneck_kernel|conv_stem_pair_pool_kernel|conv3x3_halo_c16_kernel|conv_ct_c16_kernel|conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(conv1x1_rb_kernel|conv3x3_expand_rb_kernel|conv_bneck_kernel|conv_stem_pair_pool_kernel|conv3x3_halo_c16_kernel|conv3x3_halo_c_kernel|conv3x3_halo_rb_kernel|conv3x3_halo_kernel|conv3x3_halo_x3_kernel|conv_igemm_rb_kernel|conv_igemm_x3_kernel|conv_igemm_kernel|conv_head7_kernel|conv_stem_kernel)(<[^>]*>)?", name)
     if not m:
         g = re.search(r"(clahe_\w+_kernel|resample_\w+_kernel|reduce_kernel)(<[^>]*>)?", name)      # section-8f rows
         if g:
@@ -26,14 +26,14 @@ def short(name):
     a = [v.strip() for v in args[1:-1].split(",")]
     if base == "conv1x1_rb_kernel":
         return base
+    if base == "conv3x3_expand_rb_kernel":       # <PH, CHAIN>: CHAIN = the next block's reduce conv as a third phase (round 5)
+        return "%s<%s>%s" % (base, a[0], "[+next reduce]" if len(a) > 1 and a[1] == "true" else "")
     if base == "conv_igemm_kernel":
         return "%s<%s,%s>%s" % (base, a[0], a[1], "[norm]" if len(a) > 4 and a[4] == "true" else "")
     if base in ("conv3x3_halo_kernel", "conv3x3_halo_x3_kernel"):
         return "%s<%s>" % (base, a[1])
     if base == "conv3x3_halo_c16_kernel":        # <MODE>: the 256-column resblock conv on the 16 x 16 MFMA shapes
         return "%s<256>[mode %s]" % (base, a[0])
-    if base == "conv_ct_c16_kernel":
-        return "%s[mode %s]" % (base, a[0])
     if base == "conv3x3_halo_c_kernel":          # <BN, WGM, WGN, MODE, FORM>
         form = {"0": "", "1": "[transposed]", "2": "[stride-2]"}.get(a[4] if len(a) > 4 else "0", "")
         return "%s<%s>%s[mode %s]" % (base, a[0], form, a[3])

@@ -343,7 +343,9 @@ def test_pyramid_levels_share_launches_bitwise(cuda_device):
         print("%s 8 x %d^2, 3 levels: %d ops ran as one launch for all levels (%d launches handed in by the levels)" % (arch, size, joined, handed))
         for w, g in zip(want, got):
             assert len(w) == len(g) and all(torch.equal(a, b) for a, b in zip(w, g))
-        assert joined >= 20, (joined, handed)                              # (at 8 x 1024^2: 82 of 88; the small levels of this test pick other kernel families)
+        if arch == "resnet101":
+            assert joined >= 20, (joined, handed)                          # (at 8 x 1024^2: 82 of 88; the small levels of this test pick other kernel families; VGG16's
+                                                                            #  convs -- fused max-pools, 64 / 128 output channels -- have no multi-geometry entry: none joined)
         got2 = net.forward_many(levels)                                     # the default: one side stream per level
         torch.cuda.synchronize()
         for w, g in zip(want, got2):
