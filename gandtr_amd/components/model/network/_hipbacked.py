@@ -42,13 +42,32 @@ class HipBacked:
     _warned_no_grad = False
 
     def _hip_device(self):
-        p = next(self.parameters(), None)
-        if p is None:
-            p = next(self.buffers(), None)
-        return p.device if p is not None else torch.device("cpu")
+        ts = self._hip_tensors()
+        return ts[0].device if ts else torch.device("cpu")
+
+    def _hip_tensors(self):
+        """the module tree's parameters and buffers, listed once (walking 625 tensors of a ResNet-101 through nn.Module's generators took 0.8 of the 0.94 ms a
+        stamp cost per call); dropped whenever the module tree may hold other tensor objects (``_apply``: .to / .cuda / .half; ``load_state_dict``)"""
+        ts = self.__dict__.get("_hip_ts")
+        if ts is None:
+            ts = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_hip_ts"] = ts
+        return ts
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_hip_ts", None)
+        out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_hip_ts", None)
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_hip_ts", None)
+        out = super().load_state_dict(*args, **kwargs)
+        self.__dict__.pop("_hip_ts", None)
+        return out
 
     def _hip_stamp(self):
-        ts = list(self.parameters()) + list(self.buffers())
+        ts = self._hip_tensors()
         return (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts))
 
     def _hip_net(self, key, builder):
