@@ -283,7 +283,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         // record sets the finalize kernel sums: one per phase pair
         if (want && (gdt_conv_igemm_rb_eligible(d) || gdt_conv_halo_ct_eligible(d))) { plan.steps[i].ctf = true; plan.steps[i].stats_sets = 2; }
     }
-    for (int i = 0; i < nops && net->precision == 2; ++i) {          // f16c stem: the image as augmented fp16 pixel words
+    // f16c stem: the image as augmented fp16 pixel words.  Round 5: the exact split mode (f16x3) takes the same kernel -- its result is fp32-class (both rounding residuals of the
+    // activation and 18-19 bits of every weight ride in the padding of the same MFMAs: 1e-6 of fp64, tests/test_hip_f16c.py::test_stem_c), it reads and writes the tensors of that mode
+    // (fp32 NHWC) and replaces conv_igemm_x3<64> at 80 TFLOP/s
+    for (int i = 0; i < nops && net->precision != 0; ++i) {
         const Op& o = ops[i];
         if (o.kind != OP_CONV || o.cd.transposed || o.rowsplit || o.phases.empty() || !o.phases[0].has_aug) continue;
         if (o.in < 0 || ops[net->input_op].out != o.in) continue;
@@ -949,7 +952,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     }
             ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
             ph.has_frag = true;
-        } else if (net->precision == 2 && cin_pad == 8 && 2 * cd.cin <= 8 && o.cout_pad == 64 && cd.cout == 64 && !cd.transposed) {
+        } else if (net->precision != 0 && cin_pad == 8 && 2 * cd.cin <= 8 && o.cout_pad == 64 && cd.cout == 64 && !cd.transposed) {
             // conv_stem.hip, f16c form: W1 slots of a tap = [w_hi (cin), w_hi * 2^-8 (cin), 0 ..], W2 = [w - w_hi (cin), 0 ..]; fragments as below
             const int nks = (ph.ntaps + 1) / 2;
             std::vector<f16> p1((size_t)o.cout_pad * ph.Kpad, (f16)0.f), p2(p1.size(), (f16)0.f);

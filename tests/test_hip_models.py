@@ -212,6 +212,25 @@ def test_generator_full_f16x3_meets_1e3_everywhere(cuda_device, norm, gain):
         assert float((outs[net.out_slot].cpu() - ref).abs().max()) < 1e-3
 
 
+def test_generator_exact_mode_is_exact_with_the_fp32_class_stem(cuda_device):
+    """Round 5: the exact split mode runs its stem on conv_stem_kernel's compensated form (variant 955049: fp32-class, both rounding residuals in the padding of the same
+    MFMAs) instead of the generic three-pass kernel at 80 TFLOP/s; the mode's promise -- 1e-5 of the fp32 reference at every tap and pre-tanh -- holds with it"""
+    from gandtr_amd.engine import build_generator
+    sd = synth.generator_state(0, "instance", gain=0.02)
+    x = synth.synth_input(12, (4, 3, 256, 256), 1.0)
+    taps = (1, 3, 9, 14, 21, 24)
+    ref, feats = O.resnet_generator(x, sd, "instance", 9, taps=taps, pre_tanh=True)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16x3", pre_tanh=True)
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    assert 955049 in [v for k, v, ms, fl in net.profile() if k == 1]
+    worst = max(_rel(outs[net.tap_slots[t]].cpu(), feats[t]) for t in taps)
+    pre = _rel(outs[net.out_slot].cpu(), ref)
+    print("exact mode (f16x3) with the compensated stem: worst tap %.2e, pre-tanh %.2e" % (worst, pre))
+    assert worst < 1e-5 and pre < 1e-5, (worst, pre)
+
+
 @pytest.mark.parametrize("norm", ["instance", "batch"])
 def test_generator_tiny_f16x3(cuda_device, norm):
     from gandtr_amd.engine import build_generator
