@@ -77,6 +77,7 @@ SIGNATURES = {
     "gdt_net_profile_read": (c_int, [c_void_p, c_int, _IP, _IP, _IP, POINTER(c_double), POINTER(c_double)]),
     "gdt_net_profile_read_bytes": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_double)]),
     "gdt_net_num_ops": (c_int, [c_void_p]),
+    "gdt_net_plan_summary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _IP, c_int]),
     "gdt_ms_aggregate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gdt_whiten": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gdt_whiten_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

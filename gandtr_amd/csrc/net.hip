@@ -124,6 +124,7 @@ struct gdt_net {
     char* dev_blob = nullptr;
     size_t zeros_off = 0;
     bool finalized = false;
+    bool kcat_built = false;                // build_kcat_weights has run (at finalize, or earlier for a plan query on a graph that is not finalized yet)
     int input_op = -1;
     int precision = 0;                      // 0: fp16 activations, single MFMA pass; 1: "f16x3" (fp32 activations, split operands);
     bool head_comp = false;                 // precision mode 3: f16c with the generator head compensated too (conv_head7.hip MX pass)
@@ -1250,6 +1251,8 @@ int gdt_net_hed_head(gdt_net* net, const int* feature_tensors, const float* cons
 // append the fragment-ordered K-concatenation [W_c | W_ds] and the summed bias to the weight blob (see Op::kcat_ds); whether a forward uses it is the
 // planner's decision per geometry
 static void build_kcat_weights(gdt_net* net) {
+    if (net->kcat_built) return;
+    net->kcat_built = true;
     auto& ops = net->ops;
     std::vector<int> consumers(net->tensors.size(), 0);
     for (const Op& o : ops) {
@@ -1368,6 +1371,30 @@ static double op_bytes(const gdt_net* net, const Op& o, int n) {
     if (o.res >= 0) b += out_b;
     b += (double)o.cd.cin * o.cd.cout * o.cd.kh * o.cd.kw * sizeof(f16);
     return b;
+}
+
+// What the planner decides for a geometry, as counts (host logic only: no device call) -- so that the fusion decisions are testable without a GPU.
+// counts[0] launches of conv ops (a fused launch counts once), [1] whole Bottlenecks in one launch (conv_bneck.hip), [2] 3x3 + expand launches (conv3x3_expand_rb.hip),
+// [3] of those with the next block's reduce conv chained in, [4] projection shortcuts folded into their expand conv (K-concatenated 1x1), [5] InstanceNorms applied by
+// their consumer's staging, [6] max-pools written by their producer, [7] 1 if the stem reads the caller's image itself (calls that do not resize),
+// [8] transposed convs as one fused-phase launch, [9] stride-2 convs as the shift form
+int gdt_net_plan_summary(gdt_net* net, int n, int rh, int rw, int resize, int* counts, int n_counts) {
+    GDT_REQUIRE(net && counts && n_counts >= 10 && n >= 1 && rh >= 1 && rw >= 1, "plan summary arguments");
+    if (!net->finalized && !net->precision) build_kcat_weights(net);       // (what finalize would add: the K-concatenated shortcut weights the planner may choose)
+    Plan plan;
+    int rc = make_plan(net, n, rh, rw, plan, resize == 0);
+    if (rc != GDT_OK) return rc;
+    for (int k = 0; k < n_counts; ++k) counts[k] = 0;
+    for (size_t i = 0; i < plan.steps.size(); ++i) {
+        const Step& st = plan.steps[i];
+        const Op& o = net->ops[i];
+        if (o.kind == OP_CONV && !st.skip) ++counts[0];
+        if (o.kind == OP_CONV) { counts[1] += st.bneck; counts[2] += st.xexp; counts[3] += st.xchain >= 0; counts[4] += st.kcat; counts[8] += st.ctf; counts[9] += st.s2; }
+        if (o.kind == OP_INORM) counts[5] += st.norm_into >= 0;
+        if (o.kind == OP_MAXPOOL) counts[6] += st.skip;
+        if (o.kind == OP_INPUT) counts[7] += st.direct;
+    }
+    return GDT_OK;
 }
 
 int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops) {

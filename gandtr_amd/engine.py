@@ -167,6 +167,15 @@ class HipNet:
     def output_shapes(self, n, rh, rw):
         return list(self._geometry(n, rh, rw)[1])
 
+    PLAN_KEYS = ("conv_launches", "bottlenecks_fused", "conv3x3_expand", "chained_reduce", "shortcuts_folded", "norms_folded", "pools_fused", "direct_stem",
+                 "transposed_fused", "stride2_shift")
+
+    def plan_summary(self, n, rh, rw, resize=False):
+        """the planner's fusion decisions for a geometry as a dict of counts (gdt_net_plan_summary: host logic, no device call)"""
+        c = (ctypes.c_int * 10)()
+        _hip.check(self.lib.gdt_net_plan_summary(self.handle, n, rh, rw, int(bool(resize)), c, 10))
+        return dict(zip(self.PLAN_KEYS, list(c)))
+
     def flops(self, n, rh, rw):
         f = ctypes.c_double()
         _hip.check(self.lib.gdt_net_flops(self.handle, n, rh, rw, ctypes.byref(f)))

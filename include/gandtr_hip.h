@@ -144,6 +144,12 @@ int gdt_net_levels_joined(gdt_net* net, int* level_launches);
  * the numerator of bench.py's roofline.achieved. */
 int gdt_net_flops(gdt_net* net, int n, int rh, int rw, double* flops);
 
+/* The planner's decisions for a geometry as counts (host logic only, no device call): counts[0] conv launches (a fused launch counts once), [1] whole Bottlenecks in one
+ * launch, [2] 3x3 + expand launches, [3] of those with the next block's reduce conv chained in, [4] projection shortcuts folded into their expand conv, [5] InstanceNorms
+ * applied by their consumer's staging, [6] max-pools written by their producer, [7] 1 if the stem reads the caller's image itself (resize = 0 only), [8] transposed convs as
+ * one fused-phase launch, [9] stride-2 convs as the shift form.  n_counts >= 10.  (Diagnostics / tests; no reference counterpart.) */
+int gdt_net_plan_summary(gdt_net* net, int n, int rh, int rw, int resize, int* counts, int n_counts);
+
 /* Per-op timing for bench.py's roofline line: when enabled, gdt_net_forward records HIP events on the caller's stream
  * around every op.  gdt_net_profile_read (after the forward) returns per op: kind (0 input, 1 conv, 2 instance-norm,
  * 3 maxpool, 4 gem, 5 tap, 6 hed), the conv kernel variant (BM*1000+BN: conv_igemm_kernel<BM,BN>; 900000+BN:

@@ -104,3 +104,32 @@ def test_builder_validation():
         engine.HipNet(DEV, precision="bf16")
     with pytest.raises(RuntimeError):
         net2.forward(None)                                           # not finalized
+
+
+def test_planner_fusion_decisions_at_the_benchmarked_geometries(monkeypatch):
+    """The fusion decisions the planner takes (gdt_net_plan_summary: pure host logic) at the geometries the numbers are quoted on -- a regression guard that runs without a
+    GPU: a change of an eligibility rule that silently un-fuses a layer shows up here, not only as a slower bench line."""
+    for k in ("GDT_CONV_XEXP", "GDT_XEXP_CHAIN", "GDT_CONV_BNECK", "GDT_XEXP_PH", "GDT_NORM_FUSION", "GDT_CONV_1X1_CAT"):
+        monkeypatch.delenv(k, raising=False)
+    r101 = engine.build_embedder(synth.resnet101_state(0), DEV, finalize=False)
+    p = r101.plan_summary(32, 1024, 1024)
+    # torchvision ResNet-101 [3, 4, 23, 3] (imageretrievalnet.py:189-190): layer1's three blocks (one with a projection) and layer2's three identity blocks run as one
+    # launch each; layer3's 22 identity blocks as 3x3 + expand launches, 21 of them with the next block's reduce conv chained in; the projection shortcuts of the first
+    # blocks of layer2 / 3 / 4 ride in their expand convs; the stem reads the fp32 image itself and writes the pooled tensor
+    assert p["bottlenecks_fused"] == 6 and p["conv3x3_expand"] == 22 and p["chained_reduce"] == 21 and p["shortcuts_folded"] == 3, p
+    assert p["direct_stem"] == 1 and p["pools_fused"] == 1 and p["norms_folded"] == 0, p
+    assert p["conv_launches"] == 104 - 2 * 6 - 1 - 22 - 21 - 3, p             # 104 convs (+ the projection of layer1's first block inside its Bottleneck launch)
+    assert r101.plan_summary(32, 1024, 1024, resize=True)["direct_stem"] == 0  # a resized pyramid level packs its input first
+    small = r101.plan_summary(8, 512, 512)                                     # the small level of config 4's pyramid: too few patches for the layer3 fusion
+    assert small["conv3x3_expand"] == 0 and small["chained_reduce"] == 0, small
+    monkeypatch.setenv("GDT_XEXP_CHAIN", "0")
+    assert r101.plan_summary(32, 1024, 1024)["chained_reduce"] == 0
+    monkeypatch.delenv("GDT_XEXP_CHAIN")
+    vgg = engine.build_embedder(synth.vgg16_state(0), DEV, finalize=False)
+    assert vgg.plan_summary(32, 1024, 1024)["pools_fused"] == 4                # MaxPool2d(2, 2) x 4 in the producing convs' epilogues
+    gen = engine.build_generator(synth.generator_state(0, "instance"), DEV, finalize=False)        # default precision f16c
+    g = gen.plan_summary(64, 256, 256)
+    # p2p_networks.py:269-311: all 23 InstanceNorms are applied by their consumers' staging; both transposed convs as one fused-phase launch, both stride-2 convs as shift forms
+    assert g["norms_folded"] == 23 and g["transposed_fused"] == 2 and g["stride2_shift"] == 2 and g["conv_launches"] == 24, g
+    g1 = gen.plan_summary(1, 64, 64)
+    assert g1["norms_folded"] < 23, g1                                         # a single small image: the generic kernels, own normalisation passes
