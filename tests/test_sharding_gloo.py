@@ -38,7 +38,7 @@ def _worker(rank, world, port, n_total, q):
     assert sharding.shard_batch(x).shape[0] == hi - lo
     out = sharding.embed_sharded(_tiny_embed, x)
     if rank == 0:
-        q.put(out.clone())
+        q.put(out.clone().numpy())           # (by value: a torch tensor travels as a shared-memory handle that dies with this process -- a race with the parent's get)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,7 +51,7 @@ def test_sharded_embedding_equals_single_process(n_total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -88,7 +88,7 @@ def _topk_worker(rank, world, port, ndb, q):
     lo, hi, _ = sharding.chunk_bounds(ndb, world, rank)
     s, i = retrieval.sharded_topk(vecs[:, lo:hi], qv, k=5)
     if rank == 0:
-        q.put((s.clone(), i.clone()))
+        q.put((s.clone().numpy(), i.clone().numpy()))       # (by value, see above)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,7 +101,7 @@ def test_sharded_topk_equals_global_ranking(ndb):
     procs = [ctx.Process(target=_topk_worker, args=(r, 2, port, ndb, q)) for r in range(2)]
     for p in procs:
         p.start()
-    s, i = q.get(timeout=120)
+    s, i = (torch.from_numpy(a) for a in q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
