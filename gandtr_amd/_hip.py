@@ -72,6 +72,7 @@ SIGNATURES = {
                                 c_int, c_void_p, c_size_t, c_void_p]),
     "gdt_net_forward_levels": (c_int, [c_void_p, POINTER(Level), c_int, c_void_p]),
     "gdt_net_levels_joined": (c_int, [c_void_p, _IP]),
+    "gdt_net_set_group_factor": (c_int, [c_void_p, c_float]),
     "gdt_net_flops": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double)]),
     "gdt_net_set_profiling": (c_int, [c_void_p, c_int]),
     "gdt_net_profile_read": (c_int, [c_void_p, c_int, _IP, _IP, _IP, POINTER(c_double), POINTER(c_double)]),

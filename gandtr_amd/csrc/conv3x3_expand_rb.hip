@@ -557,6 +557,13 @@ bool gdt_conv3x3_expand_eligible(const ConvLaunch& d) {
     const long tiles = (long)d.N * ((d.W + 15) / 16) * ((d.H + ph - 1) / ph);
     const double useful = (double)d.H * d.W / ((double)((d.H + ph - 1) / ph * ph) * ((d.W + 15) / 16 * 16));
     static const int min_tiles = [] { const char* e = getenv("GDT_XEXP_MIN_TILES"); return e ? atoi(e) : 256; }();
+    if (d.group_factor > 1.f) {
+        // one of several geometries in flight together (pyramid levels on side streams): what has to fill the chip is the group.  Measured, GeM-ResNet-101 hub
+        // scales, levels concurrent: 8 x 1024^2 (128 + 72 + 32 patches of 16 x 16) 7.40 -> 6.72 ms with the fused launches, 4 x 1024^2 (116 patches) 3.88 -> 4.40,
+        // 2 x 3.16 -> 3.72, 1 x 2.85 -> 3.15: fused from ~200 patches in the group, and never below 16 of its own
+        static const int group_min = [] { const char* e = getenv("GDT_XEXP_GROUP_MIN_TILES"); return e ? atoi(e) : 192; }();
+        return (double)tiles * ph * d.group_factor >= (double)group_min * 16 && tiles * ph >= 16 * 16 && useful >= 0.85;
+    }
     return tiles * ph >= (long)min_tiles * 16 && useful >= 0.85;
 }
 

@@ -129,6 +129,9 @@ struct ConvLaunch {
     // ... CHAIN form: the NEXT block's reduce conv (1x1, x_cout -> 256, bias, ReLU) on the tile just written: r_w_frag in the fragment order of w_frag with K = x_cout,
     // r_bias [256] fp32, r_out [N][H][W][256]
     const f16* r_w_frag; const float* r_bias; f16* r_out;
+    // planner hint: this geometry runs CONCURRENTLY with others of the same net (the levels of a pyramid on side streams): (pixels of all of them) / (its own), >= 1.
+    // Fusions whose tile thresholds say "enough patches to fill the chip" count the group's patches (conv3x3_expand_rb.hip)
+    float group_factor;
 };
 
 // ---- several independent geometries in ONE launch (round 5: the levels of a multi-scale pyramid, wrapper.py:221-233 / network.py:139-140) ----

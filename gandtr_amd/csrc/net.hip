@@ -137,6 +137,7 @@ struct gdt_net {
     std::vector<double> last_flops;
     std::vector<double> last_bytes;         // algorithmic HBM bytes per op (op_bytes), merged like last_flops when ops are fused
     std::vector<int> last_variant;          // kernel variant per conv op (see gdt_launch_conv)
+    float group_factor = 1.f;               // planner hint (gdt_net_set_group_factor): the geometry planned next runs concurrently with others; (their pixels + its own) / its own
     int last_joined = 0, last_level_launches = 0;   // gdt_net_forward_levels: ops whose levels shared ONE launch / launches handed back by the levels in total
 
     size_t blob_append(const void* data, size_t bytes) {
@@ -497,6 +498,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         conv_geometry(net, b, b.phases[0], N, T[b.in], d);
         d.w_frag = (const f16*)net; d.x_w_frag = (const f16*)net; d.bias = (const float*)net; d.x_bias = (const f16*)net;        // non-null markers only
         d.res = (const f16*)net; d.out = (f16*)net; d.x_cout = c.cd.cout; d.relu = 1;
+        d.group_factor = net->group_factor;
         if (!gdt_conv3x3_expand_eligible(d)) continue;
         plan.steps[i].xexp = true; plan.steps[i + 1].skip = true;
         // ... chained with the next block's reduce conv (torchvision Bottleneck.conv1 of the following block): 1x1, stride 1, C -> 256, bias, ReLU, no residual,
@@ -1456,6 +1458,7 @@ struct LevelCtx {
     const float* x; int n, h, w, rh, rw; float rscale;
     void* const* outputs; char* ws;
     Plan plan; std::vector<Tensor> T;
+    float group_factor = 1.f;                    // the planner hint this geometry was planned with (gdt_net_set_group_factor)
 };
 enum { DEFER_NONE = 0, DEFER_CONV = 1, DEFER_BNECK = 2 };
 // a launch a step WOULD make, handed back instead of issued: the lock-step driver (several geometries per forward) joins the levels' launches of one op
@@ -1545,6 +1548,7 @@ int exec_step(gdt_net* net, LevelCtx& c, const Step& stp, hipStream_t st, Deferr
                     d.x_bias = (const f16*)(net->dev_blob + oc.bias_frag_off);          // (the bias as a weight fragment)
                     d.x_cout = oc.cd.cout;
                     d.res = tptr(oc.res); d.out = tptr(oc.out);
+                    d.group_factor = c.group_factor;
                     GDT_REQUIRE(gdt_conv3x3_expand_eligible(d), "planned 3x3 + expand launch is not eligible at run time");
                     if (stp.xchain >= 0) {
                         const Op& a2 = net->ops[stp.xchain];
@@ -1817,6 +1821,7 @@ int plan_level(gdt_net* net, LevelCtx& c, void* workspace, size_t workspace_byte
     }
     c.ws = (char*)(((uintptr_t)workspace + ALIGN - 1) / ALIGN * ALIGN);
     c.T = net->tensors;
+    c.group_factor = net->group_factor;
     return GDT_OK;
 }
 
@@ -1838,6 +1843,12 @@ int gdt_net_forward(gdt_net* net, const float* x, int n, int h, int w, int rh, i
     return forward_levels(net, &c, 1, (hipStream_t)stream);
 }
 
+int gdt_net_set_group_factor(gdt_net* net, float factor) {
+    GDT_REQUIRE(net && factor >= 1.f && factor < 1e6f, "group factor >= 1");
+    net->group_factor = factor;
+    return GDT_OK;
+}
+
 int gdt_net_levels_joined(gdt_net* net, int* level_launches) {
     if (!net) return 0;
     if (level_launches) *level_launches = net->last_level_launches;
@@ -1848,8 +1859,13 @@ int gdt_net_forward_levels(gdt_net* net, const gdt_level* levels, int n_levels, 
     GDT_REQUIRE(net && net->finalized, "net must be finalized");
     GDT_REQUIRE(levels && n_levels >= 1 && n_levels <= GDT_MAX_LEVELS, "1..4 geometries per call");
     std::vector<LevelCtx> cx(n_levels);
+    double group_px = 0.0;
+    for (int l = 0; l < n_levels; ++l) group_px += (double)levels[l].n * levels[l].rh * levels[l].rw;
+    const float saved_factor = net->group_factor;
+    struct Restore { gdt_net* n; float f; ~Restore() { n->group_factor = f; } } restore{net, saved_factor};
     for (int l = 0; l < n_levels; ++l) {
         const gdt_level& g = levels[l];
+        if (n_levels > 1 && g.n >= 1 && g.rh >= 1 && g.rw >= 1) net->group_factor = (float)(group_px / ((double)g.n * g.rh * g.rw));
         GDT_REQUIRE(g.x && g.n >= 1 && g.h >= 1 && g.w >= 1 && g.rh >= 1 && g.rw >= 1, "input geometry");
         GDT_REQUIRE(g.n_outputs == (int)net->out_ops.size() && (g.outputs || g.n_outputs == 0), "output count");
         GDT_REQUIRE((long)g.n * g.rh * g.rw < (1l << 31) && (long)g.n * g.h * g.w < (1l << 31), "N*H*W must stay below 2^31");

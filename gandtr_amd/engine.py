@@ -146,7 +146,7 @@ class HipNet:
     def _geometry(self, n, rh, rw):
         """(workspace bytes, output shapes) of a geometry, planned once: every query plans the whole graph (make_plan, csrc/net.hip: ~0.1 ms for ResNet-101), and a
         forward asks three times per pyramid level -- 1.2 ms of the 8.6 ms a synchronised multi-scale call took (round 5)."""
-        key = (n, rh, rw) + tuple(os.environ.get(k) for k in self._PLAN_KNOBS)
+        key = (n, rh, rw, getattr(self, "_group_factor", 1.0)) + tuple(os.environ.get(k) for k in self._PLAN_KNOBS)
         cache = self.__dict__.setdefault("_geo_cache", {})
         hit = cache.get(key)
         if hit is None:
@@ -204,6 +204,14 @@ class HipNet:
 
     def workspace_bytes(self, n, rh, rw):
         return self._geometry(n, rh, rw)[0]
+
+    def set_group_factor(self, factor):
+        """planner hint for the geometry planned next: it runs concurrently with others of this net; factor = (pixels of all of them) / (its own), 1 = alone
+        (gdt_net_set_group_factor).  forward_many sets it per level and resets it."""
+        factor = max(1.0, float(factor))
+        if factor != getattr(self, "_group_factor", 1.0):
+            _hip.check(self.lib.gdt_net_set_group_factor(self.handle, factor))
+            self._group_factor = factor
 
     def _launch(self, x, n, h, w, rh, rw, rscale, ws, outs):
         optrs = (ctypes.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
@@ -279,7 +287,9 @@ class HipNet:
             pools["streams"].append(torch.cuda.Stream(device=dev))
             pools["ws"].append(None)
         results = []
-        with torch.cuda.device(dev):
+        group_px = float(sum(x.shape[0] * math.prod(self.resized_size(x.shape[2], x.shape[3], s)) for x, s in inputs if x.dim() == 4))
+        try:
+          with torch.cuda.device(dev):
             for k, (x, scale) in enumerate(inputs):
                 if x.dim() != 4 or x.shape[1] != self.in_channels:
                     raise ValueError("expected an N x %s x H x W input, got %s" % (self.in_channels, tuple(x.shape)))
@@ -287,6 +297,7 @@ class HipNet:
                 n, _, h, w = x.shape
                 rh, rw = self.resized_size(h, w, scale)
                 rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
+                self.set_group_factor(round(group_px / float(n * rh * rw), 3))       # the levels run together: fusion thresholds count the group's patches
                 need = self.workspace_bytes(n, rh, rw)
                 shapes = self.output_shapes(n, rh, rw)
                 st = pools["streams"][k]
@@ -309,6 +320,8 @@ class HipNet:
                     if w is not None:
                         w.record_stream(cur)
                         pools["ws"][k] = None
+        finally:
+            self.set_group_factor(1.0)
         return results
 
     MAX_LEVELS = 4          # GDT_MAX_LEVELS (csrc/gdt_common.h): geometries per gdt_net_forward_levels call
@@ -337,12 +350,14 @@ class HipNet:
                 group = inputs[lo:lo + self.MAX_LEVELS]
                 levels = (_hip.Level * len(group))()
                 keep = []
+                group_px = float(sum(x.shape[0] * math.prod(self.resized_size(x.shape[2], x.shape[3], s)) for x, s in group if x.dim() == 4))
                 for k, (x, scale) in enumerate(group):
                     if x.dim() != 4 or x.shape[1] != self.in_channels:
                         raise ValueError("expected an N x %s x H x W input, got %s" % (self.in_channels, tuple(x.shape)))
                     x = x.to(dev).contiguous().float()
                     n, _, h, w = x.shape
                     rh, rw = self.resized_size(h, w, scale)
+                    self.set_group_factor(group_px / float(n * rh * rw) if len(group) > 1 else 1.0)      # (gdt_net_forward_levels plans each level with the same factor)
                     need = self.workspace_bytes(n, rh, rw)
                     if pools["ws"][k] is None or pools["ws"][k].numel() < need:
                         pools["ws"][k] = None
@@ -356,6 +371,7 @@ class HipNet:
                     lv.workspace, lv.workspace_bytes = pools["ws"][k].data_ptr(), pools["ws"][k].numel()
                     keep.append((x, optrs))
                     results.append(outs)
+                self.set_group_factor(1.0)
                 _hip.check(self.lib.gdt_net_forward_levels(self.handle, levels, len(group), cur.cuda_stream))
                 del keep
             held = sum(w.numel() for w in pools["ws"] if w is not None)

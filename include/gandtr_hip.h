@@ -136,6 +136,11 @@ typedef struct gdt_level {
     void* workspace; size_t workspace_bytes;
 } gdt_level;
 int gdt_net_forward_levels(gdt_net* net, const gdt_level* levels, int n_levels, void* stream);
+/* Planner hint for geometries that run CONCURRENTLY on one device (the levels of a pyramid issued on side streams): factor = (pixels of all geometries in flight) /
+ * (pixels of the geometry planned next), >= 1; 1 = alone (the default).  Fusions whose tile thresholds mean "enough patches to fill the chip" then count the
+ * group's patches.  It applies to every later plan (gdt_net_workspace_bytes, gdt_net_output_shape, gdt_net_plan_summary, gdt_net_forward) until set again;
+ * gdt_net_forward_levels sets it per level itself.  Host calls on one handle are serialised (see the threading note above). */
+int gdt_net_set_group_factor(gdt_net* net, float factor);
 /* diagnostics of the last gdt_net_forward_levels call: returns the number of ops whose levels ran as ONE launch; *level_launches = launches the levels handed
  * to the lock-step driver in total (joined or not) */
 int gdt_net_levels_joined(gdt_net* net, int* level_launches);

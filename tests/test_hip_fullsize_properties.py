@@ -182,6 +182,34 @@ def test_resnet101_hub_default_pyramid_at_1024_against_oracle(cuda_device):
     assert cos >= 0.9999 and err <= 1e-3, (cos, err)
 
 
+def test_config4_per_rank_workload_against_oracle(cuda_device):
+    """BASELINE config 4's per-rank workload as it runs since round 5: 8 x 3 x 1024 x 1024, hub-default pyramid, the three levels concurrently on side streams WITH the
+    planner's group hint -- the layer3 fusion (3x3 + expand + the next block's reduce conv in one launch) is then chosen for levels that would not fuse alone (128 + 72 +
+    32 patches fill the chip together).  Two of the eight images against O.embed_ms_whiten: cosine >= 0.9999, ||d||inf <= 1e-3; and the plan the hint produces."""
+    from oracle import gandtr_oracle as O
+    sd = synth.resnet101_state(0, p=3.0)
+    lw = synth.whitening_state(0, 2048)
+    P, m = torch.from_numpy(lw["P"]), torch.from_numpy(lw["m"])
+    x = synth.synth_input(46, (8, 3, 1024, 1024))
+    scales = O.SCALE_PRESETS[True]
+    net = engine.build_embedder(sd, cuda_device)
+    alone = net.plan_summary(8, 1024, 1024)
+    net.set_group_factor(1.75)
+    grouped = net.plan_summary(8, 1024, 1024)
+    net.set_group_factor(1.0)
+    assert alone["conv3x3_expand"] == 0 and grouped["conv3x3_expand"] == 22 and grouped["chained_reduce"] == 21, (alone, grouped)
+    xd = x.to(cuda_device)
+    per_scale = torch.stack([o[net.out_slot] for o in net.forward_many([(xd, s) for s in scales])])       # S x 8 x D
+    assert net.plan_summary(8, 1024, 1024) == alone                                                          # (the hint is reset after the call)
+    got = engine.whiten(engine.ms_aggregate(per_scale, 3.0), P.to(cuda_device), m.to(cuda_device)).cpu()
+    for i in (0, 7):
+        ref = O.embed_ms_whiten(x[i:i + 1], sd, "resnet101", scales, P, m).reshape(-1)
+        cos = float(torch.nn.functional.cosine_similarity(got[i], ref, dim=0))
+        err = float((got[i] - ref).abs().max())
+        print("config 4 per-rank workload (8 x 1024^2, grouped plan), image %d: cos %.7f, |d|inf %.2e" % (i, cos, err))
+        assert cos >= 0.9999 and err <= 1e-3, (i, cos, err)
+
+
 def test_descriptor_op_identities(cuda_device):
     v = torch.rand(3, 5, 256, device=cuda_device) + 0.1
     same = v[:1].expand(3, 5, 256).contiguous()

@@ -122,6 +122,15 @@ def test_planner_fusion_decisions_at_the_benchmarked_geometries(monkeypatch):
     assert r101.plan_summary(32, 1024, 1024, resize=True)["direct_stem"] == 0  # a resized pyramid level packs its input first
     small = r101.plan_summary(8, 512, 512)                                     # the small level of config 4's pyramid: too few patches for the layer3 fusion
     assert small["conv3x3_expand"] == 0 and small["chained_reduce"] == 0, small
+    # ... unless it runs CONCURRENTLY with the other levels (the planner's group hint, gdt_net_set_group_factor): 8 x 1024^2 has 128 patches of 16 x 16 in layer3,
+    # the hub-default pyramid 128 + 72 + 32 -- together they fill the chip, and the fused launches win (measured: 7.40 -> 6.72 ms); below ~200 in the group they lose
+    eight = r101.plan_summary(8, 1024, 1024)
+    assert eight["conv3x3_expand"] == 0, eight
+    r101.set_group_factor(1.75)
+    assert r101.plan_summary(8, 1024, 1024)["conv3x3_expand"] == 22 and r101.plan_summary(4, 1024, 1024)["conv3x3_expand"] == 0
+    assert r101.workspace_bytes(8, 1024, 1024) > 0
+    r101.set_group_factor(1.0)
+    assert r101.plan_summary(8, 1024, 1024) == eight
     monkeypatch.setenv("GDT_XEXP_CHAIN", "0")
     assert r101.plan_summary(32, 1024, 1024)["chained_reduce"] == 0
     monkeypatch.delenv("GDT_XEXP_CHAIN")
