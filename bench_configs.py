@@ -52,6 +52,20 @@ def rate(fn, units, steps=8, warmup=2):
     return round(units / dt, 1), round(dt * 1e3, 2)
 
 
+def rate_back_to_back(fn, units, steps=8, warmup=2):
+    """(units per second, ms per call) of `steps` calls issued back to back between two synchronisations -- bench.py's protocol (the driver's contract): the host
+    issues call k + 1 while the device works on call k.  `rate` above synchronises after every call and so measures a call's LATENCY, host issue time included."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return round(units / dt, 1), round(dt * 1e3, 2)
+
+
 def _c3_network(dev, scales, tmp):
     """gem_resnet101 as the hub's pretrained call path builds it: checkpoint + lw.pkl -> whitening + multi-scale wrappers"""
     base = hubconf.gem_resnet101_hedngan(pretrained=False, device="cpu")
@@ -283,9 +297,12 @@ def main(args):
             runtime = {"wrappers": {"train": None, "eval": {"0_cirwhiten": {"whitening": os.path.join(tmp, "lw.pkl"), "dimensions": None},
                                                             "1_cirmultiscale": {"scales": scales}}}}
             net = N.initialize_network(None, dev, Checkpoints.load_network(os.path.join(tmp, "r101.pth")), runtime).eval()
-            r, ms = rate(lambda: net(x), 8, steps=4, warmup=1)
+            rl, msl = rate(lambda: net(x), 8, steps=4, warmup=1)
+            r, ms = rate_back_to_back(lambda: net(x), 8, steps=8, warmup=2)
             gf = 574.8 if scales is True else 1151.9
             out["c3_gem_resnet101_ms_%s_8x1024" % tag] = {"descriptors_per_s": r, "ms_per_batch": ms, "tflops": round(r * gf / 1e3, 1),
+                                                          "synchronised_per_call": {"descriptors_per_s": rl, "ms_per_call": msl,
+                                                                                    "note": "a call's latency: ~300 launches issued by the host before the device can finish"},
                                                           "roofline": _roofline_of(net.model, x),      # (the full-size level of the pyramid, 8 x 1024^2)
                                                           "roofline_note": "per-kernel figures of the scale-1 level alone (8 x 3 x 1024 x 1024); the three levels run concurrently on side streams"}
             if not args.no_cpu_baseline:
@@ -297,7 +314,7 @@ def main(args):
                     lambda: O.embed_ms_whiten(xc, sdr, "resnet101", sc, Pm[0], Pm[1]), 1, "descriptors/s", "1x3x1024x1024 images, %d-level pyramid + whitening" % len(sc), seconds=6.0)
             if scales is True:                      # the same network on a batch of 32 (what a rank holds when the global batch is 256): the large-geometry kernels apply
                 x32 = synth.synth_input(5, (32, 3, 1024, 1024)).to(dev)
-                r32, ms32 = rate(lambda: net(x32), 32, steps=4, warmup=1)
+                r32, ms32 = rate_back_to_back(lambda: net(x32), 32, steps=4, warmup=1)
                 out["c3_gem_resnet101_ms_%s_32x1024" % tag] = {"descriptors_per_s": r32, "ms_per_batch": ms32, "tflops": round(r32 * gf / 1e3, 1)}
                 del x32
             del net

@@ -152,6 +152,7 @@ struct MultiConv {
     int vblocks[GDT_MAX_LEVELS];         // virtual blocks (tile walk length) of each level
     ConvLaunch lev[GDT_MAX_LEVELS];
 };
+static_assert(sizeof(MultiConv) <= 4096, "kernel arguments are limited to 4 KB");
 __device__ __forceinline__ int gdt_multi_level(const int nlev, const int* prefix, const int b) {
     int l = 0;
 #pragma unroll
