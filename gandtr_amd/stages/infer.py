@@ -72,7 +72,7 @@ def _pixel_budget(kind):
 
 def _is_allocation_failure(err):
     text = str(err).lower()
-    return isinstance(err, torch.cuda.OutOfMemoryError) or "out of memory" in text or "hipmalloc" in text or "workspace" in text
+    return isinstance(err, torch.cuda.OutOfMemoryError) or "out of memory" in text or "hipmalloc" in text
 
 
 def _infer_grouped(network, items, kind, mean_std, device, max_batch, t0):
