@@ -325,7 +325,9 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
     }
     for (int j = 0; j < nops && allow_norm_fusion; ++j) {
         const Op& oj = ops[j];
-        if (oj.kind != OP_INORM || net->precision == 1) continue;     // f16x3: measured neutral
+        // f16x3: the patch kernel folds a plain InstanceNorm (+ReLU) only (no residual, no write-back); GDT_X3_NORM_FOLD=0 switches that off (round 1 measured it neutral)
+        static const bool x3_fold = [] { const char* e = getenv("GDT_X3_NORM_FOLD"); return !e || atoi(e) != 0; }();
+        if (oj.kind != OP_INORM || (net->precision == 1 && !x3_fold)) continue;
         // plain norm(+ReLU): exactly one consumer.  norm + residual (ResnetBlock output): the tensor itself is still needed
         // later (as the next block's residual), so the consuming conv also writes it out -- every other consumer must come
         // after that conv in program order.
@@ -398,7 +400,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         d.out = (ok.cd.out_f32_nchw || ok.rowsplit) ? nullptr : (f16*)net;         // non-null marker only
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
         d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
-        const bool fold = net->precision ? gdt_conv_halo_x3_eligible(d)
+        const bool fold = net->precision ? (!wb && oj.res < 0 && gdt_conv_halo_x3_eligible(d))
                                          : (gdt_conv_halo_eligible(d) || (!wb && (gdt_conv_igemm_norm_eligible(d) || irb_norm_ok(d))));
         if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
         static const bool plan_dbg = getenv("GDT_PLAN_DEBUG") != nullptr;
