@@ -528,7 +528,7 @@ def main():
                 "whole_net_tflops_per_gpu": round(gen_tflops, 1),
                 "timed_region_s": round(gen_ms * a.steps / 1e3, 3),
                 "steady_state_note": "a timed region under ~1 s (the driver's --steps 20: 0.2 s) runs at clocks the part does not hold; the default 100-step run of "
-                                     "the same build measures 6.15-6.26 k images/s (profiles/r04_bench_line.json)",
+                                     "the same build measures 6.03-6.35 k images/s on three boxes of the pool (profiles/r05_bench_line*.json)",
                 # measured in THIS run when the CPU baseline runs (N = 1): HIP output of the baseline's own images, taken from inside the timed batch, against the
                 # fp32 CPU oracle; null otherwise.  The asserting tests: tests/test_hip_models.py, test_hip_fullsize_properties.py, test_hip_golden.py
                 "parity_measured": None,
