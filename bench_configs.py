@@ -434,7 +434,7 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--dry-run", action="store_true", help="configs 4 / 5 sharded over N gloo ranks on the CPU, tiny images, bitwise check against one process")
     ap.add_argument("--global-batch", type=int, default=0, help="sharded configs: images in the global batch (default: 8 / 128 per rank; any N, the ranks need not divide it)")
     ap.add_argument("--small", action="store_true", help="sharded configs on the GPU with small images (2 x 256^2 / 8 x 64^2 per rank): the RCCL path's functional test")

@@ -52,10 +52,14 @@ def embed_sharded(embed_fn, x, group=None):
         local = local.reshape(-1, hi - lo).t().contiguous()       # (D,) for a single image (the hub's whitening wrappers squeeze), D x n otherwise
     else:
         local = None
-    d = torch.tensor([0 if local is None else local.shape[1]], device=x.device if x.is_cuda else "cpu")
-    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)       # ranks with an empty chunk learn D
-    if local is None:
-        local = torch.zeros((0, int(d.item())), dtype=torch.float32, device=x.device if x.is_cuda else "cpu")
+    # ranks with an empty chunk learn D from the others.  Whether ANY rank's chunk is empty follows from (N, world) alone, so every rank knows without asking
+    # whether this extra collective is needed: the usual case (N >= world) runs exactly one exchange step, the all-gather
+    _, _, chunk = chunk_bounds(x.shape[0], world, rank)
+    if (world - 1) * chunk >= x.shape[0]:
+        d = torch.tensor([0 if local is None else local.shape[1]], device=x.device if x.is_cuda else "cpu")
+        dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+        if local is None:
+            local = torch.zeros((0, int(d.item())), dtype=torch.float32, device=x.device if x.is_cuda else "cpu")
     return all_gather_descriptors(local, x.shape[0], group)
 
 
