@@ -34,6 +34,23 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, k):
+    """The k-th side stream of ``device``, shared by every net of the process.  torch hands out streams from a pool of 32 per device round-robin and the ROCm runtime
+    multiplexes them onto a few hardware queues (four by default): the first net of a process got pool streams that sit on queues of their own, the third net's
+    landed on the queue of the DEFAULT stream -- its pyramid levels then queued behind each other and every launch cost the host twice as much (measured: the
+    same batch-1 multi-scale loop at 360 descriptors/s in a fresh process and 205 after two other networks had run in it).  One list per device keeps every net
+    on the same first streams."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) <= k:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[k]
+
+
 class HipNet:
     """One layer graph living on one GPU.  Host calls are serialised per handle (one thread at a time; see forward_many for what may overlap on the device)."""
 
@@ -284,7 +301,7 @@ class HipNet:
         cur = torch.cuda.current_stream(dev)
         pools = self.__dict__.setdefault("_side", {"streams": [], "ws": []})
         while len(pools["streams"]) < len(inputs):
-            pools["streams"].append(torch.cuda.Stream(device=dev))
+            pools["streams"].append(side_stream(dev, len(pools["streams"])))
             pools["ws"].append(None)
         results = []
         group_px = float(sum(x.shape[0] * math.prod(self.resized_size(x.shape[2], x.shape[3], s)) for x, s in inputs if x.dim() == 4))
@@ -342,7 +359,7 @@ class HipNet:
         cur = torch.cuda.current_stream(dev)
         pools = self.__dict__.setdefault("_side", {"streams": [], "ws": []})
         while len(pools["ws"]) < min(len(inputs), self.MAX_LEVELS):
-            pools["streams"].append(torch.cuda.Stream(device=dev))
+            pools["streams"].append(side_stream(dev, len(pools["streams"])))
             pools["ws"].append(None)
         results = []
         with torch.cuda.device(dev):
@@ -388,7 +405,7 @@ class HipNet:
             sx = x.clone()
             ws = torch.empty(need, dtype=torch.uint8, device=x.device)
             outs = [torch.empty(s, dtype=torch.float32, device=x.device) for s in shapes]
-            side = torch.cuda.Stream(device=x.device)
+            side = side_stream(x.device, 0)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):           # warm-up outside capture (lazy function attributes etc.)
                 self._launch(sx, n, h, w, rh, rw, rscale, ws, outs)
