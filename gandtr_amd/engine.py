@@ -254,7 +254,7 @@ class HipNet:
         rscale = float(np.float32(1.0 / scale)) if scale is not None else 1.0
         key = (n, h, w, rh, rw, rscale)
         with torch.cuda.device(x.device):
-            entry = self._graphs.get(key)
+            entry = self._graphs.get(key) if (self.use_graphs and not getattr(self, "_profiling", False)) else None      # (a profiled forward runs eagerly: events per op)
             if entry is not None:
                 self._graphs.move_to_end(key)
                 entry["x"].copy_(x)
