@@ -152,6 +152,10 @@ def kernel_name(variant):
         return "conv3x3_expand_rb_kernel<%d>[+next reduce]" % ((variant - 938000) * 8)   # ... + the next block's reduce conv (phase C)
     if variant >= 935000:                                   # (+1: the projection-shortcut form)
         return "conv_bneck_kernel<%d>%s" % ((variant - 935000) & ~1, "[projection]" if (variant & 1) else "")
+    if variant >= 932000:
+        return "conv3x3_halo_x3_kernel<%d>[stride-2]" % (variant - 932000)      # FORM 2: 2 x 2 shifts over the space-to-depth view
+    if variant >= 931000:
+        return "conv3x3_halo_x3_kernel<%d>[transposed phase]" % (variant - 931000)   # FORM 1: the phase launches of a transposed conv
     if variant >= 930000:
         return "conv3x3_halo_x3_kernel<%d>" % (variant - 930000)
     if variant >= 920000:

@@ -3,10 +3,21 @@
 //
 // One workgroup = 16x16 output patch x 128 output channels, 8 wavefronts (4 x 2, 64x64 per wave, two accumulator sets).
 // Per 32-channel chunk the 18x18 fp32 halo is read once through registers (global_load_dwordx4), optionally normalised
-// (fused InstanceNorm + ReLU of the producer: x -> max((x - mean) * rstd, 0), p2p_networks.py:29,:272), split into
+// (fused InstanceNorm + ReLU of the producer: x -> max((x - mean) * rstd, 0), p2p_networks.py:29,:272; round 5: also the
+// second norm of a ResnetBlock, x + IN(conv(.)) p2p_networks.py:503-506, with the transformed tensor written back for the
+// block's later consumers by the column tile 0 workgroup -- interior pixels of its patch only), split into
 // hi / lo fp16 images and written to LDS; the 9 taps then run against it.  The pre-split weights stream per tap with
 // global_load_lds.  Halo pieces of the next chunk are issued one per tap step and written one step later
 // (issue-early / write-late), so their latency hides under a whole step of MFMAs.
+//
+// FORM 1 / 2 (round 5): the generator's shift layers on the same skeleton instead of the generic K-step-32 GEMM (conv_igemm_x3.hip gathers every input
+// pixel once per tap; 91-115 TFLOP/s):
+//   FORM 1  any tap table inside the 3 x 3 window with a strided output grid -- the four sub-pixel phase launches of ConvTranspose2d(k3,s2,p1,op1)
+//           (p2p_networks.py:295-300; 1 / 2 / 2 / 4 taps, output pixel (2y + py, 2x + px));
+//   FORM 2  Conv2d(k3,s2,p1) (p2p_networks.py:278-280) as a 2 x 2-shift convolution over the virtual space-to-depth view of its input (conv3x3_halo_c.hip FORM 2:
+//           K index = shift * 4 Cin + parity * Cin + c); a 32-channel chunk has one parity, the (shift, parity) pairs that do not occur are skipped as whole steps.
+//   With 1-4 steps per chunk there is no tap step per halo piece: the six pieces of the next chunk are issued in the chunk's first step and written after the
+//   MFMAs of its last one.
 #include <cstdlib>
 
 #include "gdt_common.h"
@@ -28,14 +39,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst, 16, 0, 0);
 }
 
+template <int FORM>
 __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d) {
+    constexpr bool BURST = FORM != 0, S2D = FORM == 2;
     constexpr int WGN = 2, WTM = 64, WTN = 64, TM = 2, TN = 2;      // 4 x 2 wavefronts, 64 x 64 per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][A hi, A lo] [2][B hi, B lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const float* __restrict__ in = (const float*)d.in;
 
-    const int tiles_x = (d.W + 15) >> 4, tiles_y = (d.H + 15) >> 4;
+    // the patch grid: the output grid of the launch (FORM 0: = input = output; 1: the phase grid = input; 2: the output = space-to-depth grid)
+    const int GH = d.OHg, GW = d.OWg;
+    const int lcr = d.lc8 + 3 - (S2D ? 2 : 0);                       // log2 of the REAL input channel count (FORM 2: d.Cin counts the 4 parities)
+    const int tiles_x = (GW + 15) >> 4, tiles_y = (GH + 15) >> 4;
     const int tpi = tiles_x * tiles_y, ntm = d.N * tpi, ntn = d.CoutPad / BN;
     int tile_m, tile_n;
     if (!gdt_tile_of_block(blockIdx.x, ntm, ntn, tile_m, tile_n)) return;      // XCD-chunked, see gdt_common.h
@@ -45,38 +61,57 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
     // ---- halo staging state: this thread owns the 4-channel group c4 = tid & 7 of halo rows (tid >> 3) + 64*r
     const int c4 = tid & 7, hrow = tid >> 3;
     const bool refl = d.pad_reflect != 0;
-    int a_pix[6]; unsigned a_ok = 0;
+    const float* __restrict__ inres = (const float*)d.in_res;
+    float* __restrict__ inout = tile_n == 0 ? (float*)d.in_out : nullptr;
+    int a_pix[6]; unsigned a_ok = 0, a_int = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int h = r * 64 + hrow;
         const int hy = h / HALO_W, hx = h - hy * HALO_W;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        int ry = iy < 0 ? -iy : (iy >= d.H ? 2 * d.H - 2 - iy : iy);
-        int rx = ix < 0 ? -ix : (ix >= d.W ? 2 * d.W - 2 - ix : ix);
-        ry = min(max(ry, 0), d.H - 1); rx = min(max(rx, 0), d.W - 1);
-        const bool inb = ((unsigned)iy < (unsigned)d.H) & ((unsigned)ix < (unsigned)d.W);
-        a_pix[r] = (n * d.H + ry) * d.W + rx;
+        const int IH = S2D ? GH : d.H, IW = S2D ? GW : d.W;        // (FORM 2: halo coordinates are space-to-depth pixels (R, C) = input pixels (2R + py, 2C + px))
+        int ry = iy < 0 ? -iy : (iy >= IH ? 2 * IH - 2 - iy : iy);
+        int rx = ix < 0 ? -ix : (ix >= IW ? 2 * IW - 2 - ix : ix);
+        ry = min(max(ry, 0), IH - 1); rx = min(max(rx, 0), IW - 1);
+        const bool inb = ((unsigned)iy < (unsigned)IH) & ((unsigned)ix < (unsigned)IW);
+        a_pix[r] = S2D ? (n * d.H + 2 * ry) * d.W + 2 * rx : (n * d.H + ry) * d.W + rx;
         a_ok |= ((h < HALO_ROWS) & (inb | refl) ? 1u : 0u) << r;
+        a_int |= (((h < HALO_ROWS) & inb & (hy >= 1) & (hy <= 16) & (hx >= 1) & (hx <= 16)) ? 1u : 0u) << r;      // the patch's own pixels (write-back)
     }
     float4 nm0 = make_float4(0.f, 1.f, 0.f, 1.f), nm1 = nm0;        // (mean, rstd) x 4 channels of the chunk being staged
+    // channel offset and pixel offset of a chunk: FORM 2 -- parity (chunk * 32) / Cin of the space-to-depth view, real channels (chunk * 32) % Cin
+    auto chan_of = [&](int chunk) { return S2D ? ((chunk << 5) & ((1 << lcr) - 1)) + c4 * 4 : (chunk << 5) + c4 * 4; };
+    auto pix_of = [&](int chunk) { const int par = (chunk << 5) >> lcr; return S2D ? (par >> 1) * d.W + (par & 1) : 0; };
     auto load_norm = [&](int chunk) {
         if (!d.in_norm) return;
-        const float* p = d.in_norm + ((long)n * d.Cin + chunk * 32 + c4 * 4) * 2;
+        const float* p = d.in_norm + (((long)n << lcr) + chan_of(chunk)) * 2;
         nm0 = *(const float4*)p; nm1 = *(const float4*)(p + 4);
     };
-    auto load_piece = [&](int chunk, int r) -> float4 {
-        if (r * 64 + hrow >= HALO_ROWS_PAD) return make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!((a_ok >> r) & 1u)) return make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v = *(const float4*)(in + (((long)a_pix[r] << (d.lc8 + 3)) + chunk * 32 + c4 * 4));
-        if (d.in_norm) {
-            v.x = (v.x - nm0.x) * nm0.y; v.y = (v.y - nm0.z) * nm0.w; v.z = (v.z - nm1.x) * nm1.y; v.w = (v.w - nm1.z) * nm1.w;
-            if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        }
-        return v;
+    // a piece = the raw conv output (+ the raw residual); normalisation, residual add, write-back and the split happen one tap step later, at the LDS write
+    // (write-late: nothing waits for a load in the step that issued it)
+    struct Piece { float4 v, rv; };
+    auto load_piece = [&](int chunk, int r) -> Piece {
+        Piece p;
+        p.v = p.rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r * 64 + hrow >= HALO_ROWS_PAD) return p;
+        if (!((a_ok >> r) & 1u)) return p;
+        const long off = ((long)(a_pix[r] + pix_of(chunk)) << lcr) + chan_of(chunk);
+        p.v = *(const float4*)(in + off);
+        if (!BURST && inres) p.rv = *(const float4*)(inres + off);
+        return p;
     };
-    auto store_piece = [&](int stage, int r, const float4& v) {
+    auto store_piece = [&](int stage, int chunk, int r, const Piece& p) {
         const int row = r * 64 + hrow;
         if (row >= HALO_ROWS_PAD) return;
+        float4 v = p.v;
+        if ((a_ok >> r) & 1u) {                  // (padding pieces stay zero)
+            if (d.in_norm) {
+                v.x = (v.x - nm0.x) * nm0.y; v.y = (v.y - nm0.z) * nm0.w; v.z = (v.z - nm1.x) * nm1.y; v.w = (v.w - nm1.z) * nm1.w;
+                if (d.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (!BURST && inres) { v.x += p.rv.x; v.y += p.rv.y; v.z += p.rv.z; v.w += p.rv.w; }
+            if (!BURST && inout && ((a_int >> r) & 1u)) *(float4*)(inout + (((long)a_pix[r] << lcr) + chunk * 32 + c4 * 4)) = v;
+        }
         char* Ah = smem + stage * STAGE_A;
         const int off = row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + (c4 & 1) * 8;
         const float x[4] = {v.x, v.y, v.z, v.w};
@@ -112,34 +147,52 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
 #pragma unroll
     for (int j = 0; j < TN; ++j) { const int row = wn * WTN + j * 32 + fr; b_off[j] = row * ROWB; b_sw[j] = (row >> 2) & 3; }
 
-    const int nchunks = d.Cin >> 5;
-    const int total = nchunks * 9;
+    const int nchunks = d.Cin >> 5, ntaps = d.ntaps;
+    // the steps: (chunk, tap) pairs in order.  FORM 2 skips the (shift, parity) pairs that do not occur in a stride-2 3x3 conv: shift -1 meets parity 1 only
+    // (kernel row 0), shift 0 both (rows 1, 2) -- rows and columns alike; every chunk keeps the (0, 0) shift
+    auto live = [&](int cc, int tt) -> bool {
+        if (!S2D) return true;
+        const int par = (cc << 5) >> lcr;
+        return (((tt >> 1) | (par >> 1)) & ((tt & 1) | (par & 1))) != 0;
+    };
+    auto advance = [&](int& cc, int& tt) { do { if (++tt == ntaps) { tt = 0; ++cc; } } while (cc < nchunks && !live(cc, tt)); };
+    int c = 0, t = 0;
+    if (!live(0, 0)) advance(c, t);
     load_norm(0);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) store_piece(0, r, load_piece(0, r));
-    issue_b(0, 0);
+    for (int r = 0; r < 6; ++r) store_piece(0, 0, r, load_piece(0, r));
+    issue_b(t * d.Cin, 0);
 
-    float4 pend = make_float4(0.f, 0.f, 0.f, 0.f);       // halo piece in flight (issued in the previous step)
-    int c = 0, t = 0;
-    for (int s = 0; s < total; ++s) {
+    Piece pend[BURST ? 6 : 1];                           // halo pieces in flight (FORM 0: the one issued in the previous step)
+#pragma unroll
+    for (int r = 0; r < (BURST ? 6 : 1); ++r) pend[r].v = pend[r].rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool first_of_chunk = true;
+    for (int s = 0; c < nchunks; ++s) {
         __syncthreads();
-        const bool more = s + 1 < total;
-        int nc = c, nt = t + 1;
-        if (nt == 9) { nt = 0; nc = c + 1; }
+        int nc = c, nt = t;
+        advance(nc, nt);
+        const bool more = nc < nchunks, last_of_chunk = nc != c;
         const bool next_chunk = c + 1 < nchunks;
-        // halo of the next chunk: piece t-1 (loaded during the previous step) is split and written, piece t is issued
         if (next_chunk) {
-            if (t >= 1 && t <= 6) store_piece((c + 1) & 1, t - 1, pend);
-            if (t == 0) load_norm(c + 1);
-            if (t < 6) pend = load_piece(c + 1, t);
+            if (!BURST) {
+                // halo of the next chunk: piece t-1 (loaded during the previous step) is split and written, piece t is issued
+                if (t >= 1 && t <= 6) store_piece((c + 1) & 1, c + 1, t - 1, pend[0]);
+                if (t == 0) load_norm(c + 1);
+                if (t < 6) pend[0] = load_piece(c + 1, t);
+            } else if (first_of_chunk) {
+                load_norm(c + 1);                            // (this chunk's pieces were written at the end of the previous one)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) pend[BURST ? r : 0] = load_piece(c + 1, r);
+            }
         }
         if (more) issue_b(nt * d.Cin + (nc << 5), (s + 1) & 1);
         const char* Ah = smem + (c & 1) * STAGE_A;
         const char* Bh = smem + 2 * STAGE_A + (s & 1) * STAGE_B;
-        const int ty = (t * 21846) >> 16, tx = t - ty * 3;
+        const int ty = (t * d.invTW) >> 16, tx = t - ty * d.TW;
+        const int tap_h = (d.dy0 + ty * d.dys + 1) * HALO_W + d.dx0 + tx * d.dxs + 1;       // the tap's offset in the halo (taps lie inside the 3 x 3 window)
         int a_off[TM], a_sw[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { const int h = a_h0[i] + ty * HALO_W + tx; a_off[i] = h * ROWB; a_sw[i] = (h >> 2) & 3; }
+        for (int i = 0; i < TM; ++i) { const int h = a_h0[i] + tap_h; a_off[i] = h * ROWB; a_sw[i] = (h >> 2) & 3; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int ch = 2 * kk + fh;
@@ -163,6 +216,12 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                     accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accl[i][j], 0, 0, 0);
                 }
         }
+        if (BURST && next_chunk && last_of_chunk) {
+            __builtin_amdgcn_sched_barrier(0);               // (behind the step's MFMAs: the pieces have had the chunk to arrive)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) store_piece((c + 1) & 1, c + 1, r, pend[BURST ? r : 0]);
+        }
+        first_of_chunk = last_of_chunk;
         c = nc; t = nt;
     }
 
@@ -185,8 +244,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 for (int e = 0; e < 16; ++e) {
                     const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                     const int y = y0 + (row >> 4), x = x0 + (row & 15);
-                    const bool ok = y < d.H && x < d.W && col < d.Cout;
-                    rr[i][e] = resp[ok ? (((long)n * d.H + y) * d.W + x) * d.Cout + col : 0];
+                    const bool ok = y < GH && x < GW && col < d.Cout;
+                    rr[i][e] = resp[ok ? (((long)n * d.OH + y * d.osy + d.ooy) * d.OW + x * d.osx + d.oox) * d.Cout + col : 0];
                 }
         }
 #pragma unroll
@@ -197,8 +256,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 float v = acc[i][j][e] + accl[i][j][e] * LO_INV + bv;
                 s1 += v; s2 += v * v;
                 const int y = y0 + (row >> 4), x = x0 + (row & 15);
-                if (y >= d.H || x >= d.W || col >= d.Cout) continue;
-                const long off = (((long)n * d.H + y) * d.W + x) * d.Cout + col;
+                if (y >= GH || x >= GW || col >= d.Cout) continue;
+                const long off = (((long)n * d.OH + y * d.osy + d.ooy) * d.OW + x * d.osx + d.oox) * d.Cout + col;
                 if (resp) v += rr[i][e];
                 if (d.relu) v = fmaxf(v, 0.f);
                 outp[off] = v;
@@ -226,7 +285,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
 }  // namespace
 
 bool gdt_conv_halo_x3_eligible(const ConvLaunch& d) {
-    static const int mode = [] { const char* e = getenv("GDT_CONV_HALO"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 force
+    const char* e = getenv("GDT_CONV_HALO_X3");                 // 0 off, 1 auto, 2 force (read per call: tests force the patch kernels at small batches)
+    const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
     const bool shape = d.ntaps == 9 && d.TW == 3 && d.sy == 1 && d.sx == 1 && d.dy0 == -1 && d.dx0 == -1 && d.dys == 1 && d.dxs == 1 &&
                        d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Cin % 32 == 0 && !d.out_f32 && d.OH == d.H &&
@@ -239,8 +299,35 @@ bool gdt_conv_halo_x3_eligible(const ConvLaunch& d) {
     return tiles * (d.CoutPad / 128) >= 512 && useful >= 0.85;
 }
 
-int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) {
-    const int tiles = d.N * ((d.W + 15) / 16) * ((d.H + 15) / 16), ntn = d.CoutPad / BN;
+// FORM 1 (a tap table inside the 3 x 3 window, strided output: the phase launches of a transposed conv) and FORM 2 (d.x3_form == 2: stride-2 3x3 conv over the
+// virtual space-to-depth view, net.hip s2_geometry); plain InstanceNorm (+ReLU) folding only
+bool gdt_conv_halo_x3_taps_eligible(const ConvLaunch& d) {
+    const char* e = getenv("GDT_CONV_HALO_X3_FORMS");           // 0 off (A/B: the generic GEMM), 1 auto, 2 force (read per call)
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0 || !d.w_lo || d.out_f32 || d.in_res || d.in_out || d.pool2 || d.CoutPad % 128 != 0 || d.osy < 1 || d.osx < 1) return false;
+    if (d.x3_form == 2) {
+        const bool shape = d.ntaps == 4 && d.TW == 2 && d.dy0 == -1 && d.dys == 1 && d.dx0 == -1 && d.dxs == 1 && d.sy == 2 && d.sx == 2 && d.osy == 1 && d.osx == 1 &&
+                           d.ooy == 0 && d.oox == 0 && !d.pad_reflect && !(d.H & 1) && !(d.W & 1) && d.OH == d.H / 2 && d.OW == d.W / 2 && d.OHg == d.OH && d.OWg == d.OW &&
+                           d.Cin % 128 == 0 && d.Kpad == 4 * d.Cin;
+        if (!shape) return false;
+    } else {
+        if (d.x3_form != 0 || d.sy != 1 || d.sx != 1 || d.ntaps < 1 || d.ntaps > 9 || d.TW < 1 || d.Cin % 32 != 0 || d.Kpad != d.ntaps * d.Cin || d.OHg != d.H || d.OWg != d.W) return false;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const int dy = d.dy0 + (t / d.TW) * d.dys, dx = d.dx0 + (t % d.TW) * d.dxs;
+            if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+        }
+    }
+    if ((long)d.N * d.H * d.W * (d.x3_form == 2 ? d.Cin / 4 : d.Cin) >= (1L << 31)) return false;
+    if (d.stats && ((d.OHg & 15) || (d.OWg & 15))) return false;
+    if (mode == 2) return true;
+    const long tiles = (long)d.N * ((d.OWg + 15) / 16) * ((d.OHg + 15) / 16);
+    const double useful = (double)d.OHg * d.OWg / ((double)((d.OHg + 15) / 16 * 16) * ((d.OWg + 15) / 16 * 16));
+    return tiles * (d.CoutPad / 128) >= 512 && useful >= 0.85;
+}
+
+template <int FORM>
+static int launch_halo_x3(const ConvLaunch& d, hipStream_t stream) {
+    const int tiles = d.N * ((d.OWg + 15) / 16) * ((d.OHg + 15) / 16), ntn = d.CoutPad / BN;
     constexpr size_t lds = 2 * (size_t)STAGE_A + 2 * (size_t)STAGE_B;
     static_assert(lds <= 160 * 1024 && (size_t)4 * BN * 8 <= lds, "LDS budget");
     static GdtPerDevice per_dev;          // one attribute call per template instantiation AND device (gdt_common.h)
@@ -248,12 +335,15 @@ int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) {
     {
         const int rc = gdt_per_device(per_dev, attr_set, [](int, int, int& v) {
             v = 1;
-            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_halo_x3_kernel<FORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             return GDT_OK;
         });
         if (rc != GDT_OK) return rc;
     }
-    hipLaunchKernelGGL(conv3x3_halo_x3_kernel, dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(NT), lds, stream, d);
+    hipLaunchKernelGGL(conv3x3_halo_x3_kernel<FORM>, dim3(gdt_grid_for_tiles(tiles, ntn)), dim3(NT), lds, stream, d);
     GDT_CHECK_HIP(hipGetLastError());
     return GDT_OK;
 }
+
+int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream) { return launch_halo_x3<0>(d, stream); }
+int gdt_launch_conv_halo_x3_taps(const ConvLaunch& d, hipStream_t stream) { return d.x3_form == 2 ? launch_halo_x3<2>(d, stream) : launch_halo_x3<1>(d, stream); }

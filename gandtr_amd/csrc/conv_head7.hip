@@ -17,6 +17,7 @@
 //     (a single double-buffered workgroup measured 0.46 ms with its phases serialised by barriers).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gdt_common.h"
 
@@ -57,7 +58,13 @@ __device__ __forceinline__ void lds_barrier() {
 // registers per thread) wait in registers while the fp16 plane is consumed, are then written over it, and a second, shorter MFMA
 // pass (14 instead of 28 per block, weights streamed from L2) adds the correction.  A single fp16 pass left the head with 3.4e-4 of
 // the output range -- as much as the 22 compensated layers before it together (4.7e-4 pre-tanh overall; 3.1e-4 with this).
-template <bool F32IN, bool MX = false>
+//
+// X3 ("f16x3" precision mode, round 5): the exact split  a w = a_hi w_hi + (a_lo w_hi + a_hi w_lo) 2^-11  (conv_igemm_x3.hip) on the same skeleton.  LDS still
+// holds one plane at a time, and the lo plane (fp16: 68 registers per thread) cannot wait in registers beside two accumulator sets: the halo is read TWICE -- the
+// second time, microseconds later, from L2 / the Infinity Cache -- and split again; pass 1 runs a_hi against w_hi and w_lo (both streamed L2 -> registers), pass 2
+// a_lo against w_hi.  Replaces the generic K-step-32 GEMM + partial-sum tensor + combine launch of the mode (0.96 + 0.67 ms at 64 x 256^2) and lets the planner
+// fold the InstanceNorm in front of the head (one more 0.4 ms pass over the 1 GB tensor).
+template <bool F32IN, bool MX = false, bool X3 = false>
 __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, const int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,7 +72,8 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
     const int fr = lane & 31, fh = lane >> 5;
     const int tiles_x = (d.W + PW - 1) / PW, tiles_y = (d.H + PH - 1) / PH, tpi = tiles_x * tiles_y;
     const int cout = d.Cout;
-    static_assert(F32IN || !MX, "the compensated product reads the fp32 tensor");
+    static_assert((F32IN || !MX) && (!X3 || (F32IN && !MX)), "the compensated / exact products read the fp32 tensor");
+    constexpr bool STREAM = MX || X3;           // weight fragments streamed per tile instead of resident
 
     // XCD-chunked persistent schedule: workgroup b (XCD b & 7, slot b >> 3) walks the tiles slot, slot + S, ... of its XCD's
     // contiguous span, so the CUs of one XCD hold neighbouring tiles (shared halo rows hit its L2) at any time
@@ -83,18 +91,19 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
     // the whole B operand lives in registers: fragment ks holds k = ks * 16 + fh * 8 .. +8 of output column fr
     // (MX: the registers are needed for the fp4 words that wait for the second pass; the 28 KB matrix is then streamed L2 -> registers
     // WRING fragments ahead, once per tile -- every wave of the chip reads the same 28 KB)
-    constexpr int NBW = MX ? 1 : 4 * KT, WRING = 6;
+    constexpr int NBW = STREAM ? 1 : 4 * KT, WRING = X3 ? 4 : 6;
     f16x8 bw[NBW];
-    if (!MX) {
+    if (!STREAM) {
 #pragma unroll
         for (int ks = 0; ks < 4 * KT; ++ks) bw[ks % NBW] = *(const f16x8*)(d.w_frag + ((long)ks * 64 + lane) * 8);
     }
-    f16x8 wring[MX ? WRING : 1];
+    f16x8 wring[STREAM ? WRING : 1], wring_lo[X3 ? WRING : 1];
     // (uniform base + 32-bit lane offset, refreshed per tile behind an opaque copy: as 64-bit per-lane addresses the 28 + 42 fragment
     // addresses are loop invariants, which the compiler hoists out of the tile loop and spills)
     unsigned lo16 = 0, lo8 = 0, lo4 = 0;
     auto lane_offsets = [&]() { int l = lane; asm volatile("" : "+v"(l)); lo16 = l * 16; lo8 = l * 8; lo4 = l * 4; };
     auto load_w = [&](int ks) { wring[ks % WRING] = *(const f16x8*)((const char*)d.w_frag + ks * 1024 + lo16); };
+    auto load_wl = [&](int ks) { wring_lo[X3 ? ks % WRING : 0] = *(const f16x8*)((const char*)d.w_frag2 + ks * 1024 + lo16); };       // (X3: d.w_frag2 = the lo parts, same order)
 
     const bool refl = d.pad_reflect != 0;
     // A fragment of partial-sum pixel m = block * 32 + fr for kernel row ky: halo pixel m + ky * 38.  The swizzle term
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             a_base[ky] = row * 128 + ((fh_ ^ ((row >> 1) & 7)) << 4);
         }
     };
-    if (!MX) set_a_base(fr, fh);
+    if (!STREAM) set_a_base(fr, fh);
     // (scale, shift) of the folded InstanceNorm for 16-byte channel group tid & 7 of the current image
     const int c8 = tid & 7;
 
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             for (int k = 0; k < 4; ++k) nv[k] = *(const float4*)(d.in_norm + ((long)n * 64 + c8 * 8) * 2 + k * 4);
         }
         unsigned qq[MX ? ROUNDS : 1][2];              // (MX) fp4 words of the residual / the rounded value of the thread's pieces, 8 channels each
-        if (F32IN) {
+        auto stage_f32 = [&](auto lo_plane) {
+            constexpr bool LO = decltype(lo_plane)::value;     // (X3) the second plane: fp16((p - fp16(p)) * 2^11)
             // ---- halo through registers: thread t handles 8-channel group t & 7 of pixels (t >> 3) + 32 j
             const float* __restrict__ inf = (const float*)d.in;
             float sc[8], sh[8];
@@ -172,6 +182,13 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                         qlo = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(qlo, l0, l1, lo_scale, k);                                          \
                         qhi = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(qhi, __builtin_bit_cast(f16x2, w), hi_scale, k);                     \
                     }                                                                                                                      \
+                    if (X3 && LO) {                                                                                                        \
+                        float l0, l1;                                                                                                      \
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(w), "v"(p0));                \
+                        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(w), "v"(p1));                \
+                        l0 *= 2048.f; l1 *= 2048.f;                                                                                         \
+                        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(l0), "v"(l1));                                                   \
+                    }                                                                                                                      \
                     o[k] = ok ? w : 0u;                                                                                                    \
                 }
                 GDT_H7_PAIR(0) GDT_H7_PAIR(1) GDT_H7_PAIR(2) GDT_H7_PAIR(3)
@@ -190,6 +207,9 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                 if (MX) __builtin_amdgcn_sched_barrier(0);        // (round by round: interleaved across rounds the 17 unrolled rounds spill)
             }
             lds_barrier();
+        };
+        if (F32IN) {
+            stage_f32(std::false_type{});
         } else {
         // ---- halo: 67 wave-wide 1 KB DMA rounds (reflect / zero padding resolved in the source address)
         if (!(d.dbg & 8) || tile == span_lo + slot) {
@@ -248,41 +268,46 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
 
         // ---- GEMM over the kernel rows: 2 or 3 independent accumulator chains per wave
         int lane_t = lane;
-        if (MX) { asm volatile("" : "+v"(lane_t)); set_a_base(lane_t & 31, lane_t >> 5); }
+        if (STREAM) { asm volatile("" : "+v"(lane_t)); set_a_base(lane_t & 31, lane_t >> 5); }
         const int fr_t = lane_t & 31, fh_t = lane_t >> 5;
         const int b2 = nb == 3 ? 2 : 1;
-        f32x16 acc[3];
+        f32x16 acc[3], accl[X3 ? 3 : 1];
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[b][e] = 0.f; if (X3) accl[X3 ? b : 0][e] = 0.f; }
+        constexpr int PF = 3;                                  // fragment sets in flight (LDS latency vs 3 MFMAs per set)
+        // (MX form: every wave issues three MFMA chains -- the waves that own two blocks repeat their second one and drop the result: with
+        // the branches of the two-or-three form around 28 + 14 unrolled steps the register allocator spilled ~230 registers)
+        auto frags = [&](int ks, f16x8 (&f)[3]) {
+            const int off = a_base[ks >> 2] ^ ((ks & 3) << 5);
+            f[0] = *(const f16x8*)(smem + off);
+            f[1] = *(const f16x8*)(smem + off + NWAVE * 32 * 128);
+            if (STREAM) f[2] = *(const f16x8*)(smem + off + b2 * (NWAVE * 32 * 128));          // (b2 = 1 for the waves with two blocks: a duplicate, discarded)
+            else if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
+        };
         if (!(d.dbg & 2)) {
-            constexpr int PF = 3;                                  // fragment sets in flight (LDS latency vs 3 MFMAs per set)
-            // (MX form: every wave issues three MFMA chains -- the waves that own two blocks repeat their second one and drop the result: with
-            // the branches of the two-or-three form around 28 + 14 unrolled steps the register allocator spilled ~230 registers)
             f16x8 afr[PF][3];
-            auto frags = [&](int ks, f16x8 (&f)[3]) {
-                const int off = a_base[ks >> 2] ^ ((ks & 3) << 5);
-                f[0] = *(const f16x8*)(smem + off);
-                f[1] = *(const f16x8*)(smem + off + NWAVE * 32 * 128);
-                if (MX) f[2] = *(const f16x8*)(smem + off + b2 * (NWAVE * 32 * 128));          // (b2 = 1 for the waves with two blocks: a duplicate, discarded)
-                else if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
-            };
 #pragma unroll
             for (int p = 0; p < PF - 1; ++p) frags(p, afr[p]);
-            if (MX) {
+            if (STREAM) {
                 lane_offsets();
 #pragma unroll
-                for (int p = 0; p < WRING - 1; ++p) load_w(p);
+                for (int p = 0; p < WRING - 1; ++p) { load_w(p); if (X3) load_wl(p); }
             }
 #pragma unroll
             for (int ks = 0; ks < 4 * KT; ++ks) {
                 if (ks + PF - 1 < 4 * KT) frags(ks + PF - 1, afr[(ks + PF - 1) % PF]);
-                if (MX && ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
-                const f16x8 wk = MX ? wring[ks % WRING] : bw[ks % NBW];
+                if (STREAM && ks + WRING - 1 < 4 * KT) { load_w(ks + WRING - 1); if (X3) load_wl(ks + WRING - 1); }
+                const f16x8 wk = STREAM ? wring[ks % WRING] : bw[ks % NBW];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], wk, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], wk, acc[1], 0, 0, 0);
-                if (MX || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);
+                if (STREAM || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);
+                if (X3) {                       // a_hi w_lo
+                    const f16x8 wl = wring_lo[X3 ? ks % WRING : 0];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wl, accl[X3 ? b : 0], 0, 0, 0);
+                }
             }
         }
         lds_barrier();                                 // the halo has been consumed by every wave
@@ -329,6 +354,32 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             }
             lds_barrier();                             // the fp4 plane has been consumed
         }
+        if constexpr (X3) {
+            // ---- second plane: a_lo over the consumed halo (read again, split again), then a_lo w_hi into the correction accumulators
+            stage_f32(std::true_type{});
+            int lane_u = lane;
+            asm volatile("" : "+v"(lane_u));
+            set_a_base(lane_u & 31, lane_u >> 5);
+            f16x8 afr[PF][3];
+#pragma unroll
+            for (int p = 0; p < PF - 1; ++p) frags(p, afr[p]);
+            lane_offsets();
+#pragma unroll
+            for (int p = 0; p < WRING - 1; ++p) load_w(p);
+#pragma unroll
+            for (int ks = 0; ks < 4 * KT; ++ks) {
+                if (ks + PF - 1 < 4 * KT) frags(ks + PF - 1, afr[(ks + PF - 1) % PF]);
+                if (ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
+                const f16x8 wk = wring[ks % WRING];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wk, accl[X3 ? b : 0], 0, 0, 0);
+            }
+            lds_barrier();                             // the lo plane has been consumed
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][e] += accl[X3 ? b : 0][e] * (1.f / 2048.f);
+        }
         float* P = (float*)smem;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -371,6 +422,7 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
             GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            GDT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_head7_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             return GDT_OK;
         });
         if (rc != GDT_OK) return rc;
@@ -381,7 +433,8 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream) {
     static const int dbg = [] { const char* e = getenv("GDT_HEAD7_DBG"); return e ? atoi(e) : 0; }();
     ConvLaunch dd = d;
     dd.dbg = dbg;
-    if (d.in_f32 && d.wmx_a && d.wmx_b && d.wmx_s) hipLaunchKernelGGL((conv_head7_kernel<true, true>), dim3(grid), dim3(NT), lds, stream, dd, ntiles);
+    if (d.in_f32 && d.w_frag2) hipLaunchKernelGGL((conv_head7_kernel<true, false, true>), dim3(grid), dim3(NT), lds, stream, dd, ntiles);       // f16x3: w_frag2 = the lo parts
+    else if (d.in_f32 && d.wmx_a && d.wmx_b && d.wmx_s) hipLaunchKernelGGL((conv_head7_kernel<true, true>), dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     else if (d.in_f32) hipLaunchKernelGGL(conv_head7_kernel<true>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     else hipLaunchKernelGGL(conv_head7_kernel<false>, dim3(grid), dim3(NT), lds, stream, dd, ntiles);
     GDT_CHECK_HIP(hipGetLastError());

@@ -64,9 +64,15 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
     const bool refl = d.pad_reflect != 0;
     const int g4mask = (2 << d.lc8) - 1;                       // Cin / 4 - 1
     float4 areg[4];
+    // the producer's InstanceNorm (+ReLU) applied while staging (round 5: the stride-2 / transposed layers of the generator; a tile lies inside one image --
+    // gdt_conv_x3_norm_eligible): (mean, rstd) of the step's 4 channels travel with the pieces and are applied at the LDS write; padding stays zero
+    const float* __restrict__ nrm = d.in_norm ? d.in_norm + (long)((tile_m * BM) / hw_g) * d.Cin * 2 : nullptr;
+    float4 nm0 = make_float4(0.f, 1.f, 0.f, 1.f), nm1 = nm0;
+    unsigned a_okmask = 0;
     auto load_a = [&](int ks) {
         const int g4 = ks * 8 + c4;
         const int tap = g4 >> (d.lc8 + 1), coff = (g4 & g4mask) * 4;
+        if (nrm) { nm0 = *(const float4*)(nrm + coff * 2); nm1 = *(const float4*)(nrm + coff * 2 + 4); a_okmask = 0; }
         const int ty = (tap * d.invTW) >> 16, tx = tap - ty * d.TW;
         const int dy = d.dy0 + ty * d.dys, dx = d.dx0 + tx * d.dxs;
         const bool tap_ok = tap < d.ntaps;
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
             const int pix = a_base[r] + ry * d.W + rx;
             const float* src = in + (((long)pix << (d.lc8 + 3)) + coff);
             areg[r] = ok ? *(const float4*)src : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_okmask |= (ok ? 1u : 0u) << r;
         }
     };
     auto store_a = [&](int stage) {
@@ -89,7 +96,11 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(const ConvLaunch d) 
         for (int r = 0; r < 4; ++r) {
             const int row = r * 32 + arow;
             const int off = row * ROWB + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + (c4 & 1) * 8;
-            const float x[4] = {areg[r].x, areg[r].y, areg[r].z, areg[r].w};
+            float x[4] = {areg[r].x, areg[r].y, areg[r].z, areg[r].w};
+            if (nrm && ((a_okmask >> r) & 1u)) {
+                x[0] = (x[0] - nm0.x) * nm0.y; x[1] = (x[1] - nm0.z) * nm0.w; x[2] = (x[2] - nm1.x) * nm1.y; x[3] = (x[3] - nm1.z) * nm1.w;
+                if (d.in_relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+            }
             f16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -252,6 +263,11 @@ int launch_x3(const ConvLaunch& d, hipStream_t stream) {
 
 }  // namespace
 
+// can the generic f16x3 GEMM apply the producer's InstanceNorm (+ReLU) while it stages?  (no residual, no write-back; a 128-row tile inside one image)
+bool gdt_conv_x3_norm_eligible(const ConvLaunch& d) {
+    return d.w_lo != nullptr && !d.in_res && !d.in_out && (d.OHg * d.OWg) % 128 == 0 && d.Cin % 4 == 0;
+}
+
 int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant) {
     GDT_REQUIRE(d.Cin >= 8 && (d.Cin & (d.Cin - 1)) == 0 && (1 << d.lc8) * 8 == d.Cin, "Cin must be a power of two >= 8");
     GDT_REQUIRE(d.Kpad % 64 == 0 && d.nk == d.Kpad / BK && d.ntaps * d.Cin <= d.Kpad, "Kpad / nk (K-step 32)");
@@ -264,8 +280,10 @@ int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant) {
     }
     const int bn = gdt_conv_bn(d.Cout);
     GDT_REQUIRE(d.CoutPad % bn == 0 && d.CoutPad >= d.Cout, "CoutPad must be a multiple of the N tile");
-    if (gdt_conv_halo_x3_eligible(d)) { if (variant) *variant = 930128; return gdt_launch_conv_halo_x3(d, stream); }
-    GDT_REQUIRE(d.in_norm == nullptr, "fused input normalisation is only implemented in the halo kernels");
+    if (d.x3_form == 0 && gdt_conv_halo_x3_eligible(d)) { if (variant) *variant = 930128; return gdt_launch_conv_halo_x3(d, stream); }
+    if (gdt_conv_halo_x3_taps_eligible(d)) { if (variant) *variant = d.x3_form == 2 ? 932128 : 931128; return gdt_launch_conv_halo_x3_taps(d, stream); }
+    GDT_REQUIRE(d.x3_form == 0, "the space-to-depth view exists in the patch kernel only");
+    GDT_REQUIRE(d.in_norm == nullptr || gdt_conv_x3_norm_eligible(d), "fused input normalisation: plain norm (+ReLU), whole 128-row tiles per image");
     if (variant) *variant = 300000 + bn;
     if (bn == 128) return launch_x3<128, 2, 2>(d, stream);
     if (bn == 64) return launch_x3<64, 2, 2>(d, stream);

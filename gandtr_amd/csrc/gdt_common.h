@@ -114,6 +114,7 @@ struct ConvLaunch {
     // 4 blocks]; lane (n, blk) of a correction operand = 32 e2m3 values of fp16(w) (blk 0, 2) / w - fp16(w) (blk 1, 3) of k 0-31 (blk 0, 1) / 32-63 (blk 2, 3)
     const void* w_c16;
     int c_lo_exp, c_hi_exp;
+    int x3_form;                  // conv3x3_halo_x3.hip: 2 = Conv2d(k3,s2,p1) as 2 x 2 shifts over the virtual space-to-depth view (Cin counts the 4 parities); else 0
     int in_f32;                   // conv_head7.hip: `in` is the fp32 NHWC tensor of the f16c mode (rounded to fp16 once, while staging)
     int stagger_us;               // conv3x3_halo_c.hip: start-up delay step between the four workgroup phase groups (0: none)
     int phase_cout;               // > 0: fused ConvTranspose2d(k3,s2,p1,op1) -- GEMM column = phase * phase_cout + cout, phase = py * 2 + px,
@@ -240,6 +241,9 @@ int gdt_launch_conv_head7(const ConvLaunch& d, hipStream_t stream);
 // f16x3 precision mode (conv_igemm_x3.hip): in / res / out are fp32 NHWC (passed through the f16* fields), nk = Kpad / 32
 int gdt_launch_conv_x3(const ConvLaunch& d, hipStream_t stream, int* variant = nullptr);
 bool gdt_conv_halo_x3_eligible(const ConvLaunch& d);       // conv3x3_halo_x3.hip
+bool gdt_conv_halo_x3_taps_eligible(const ConvLaunch& d);  // ... FORM 1 / 2: tap tables inside the 3 x 3 window (transposed-conv phases), stride 2 over the space-to-depth view
+int gdt_launch_conv_halo_x3_taps(const ConvLaunch& d, hipStream_t stream);
+bool gdt_conv_x3_norm_eligible(const ConvLaunch& d);       // conv_igemm_x3.hip: the generic f16x3 GEMM applies the producer's InstanceNorm (+ReLU) while staging
 int gdt_launch_conv_halo_x3(const ConvLaunch& d, hipStream_t stream);
 bool gdt_conv_halo_c_eligible(const ConvLaunch& d);         // conv3x3_halo_c.hip (f16c mode, variant 970256)
 int gdt_launch_conv_halo_c(const ConvLaunch& d, hipStream_t stream);

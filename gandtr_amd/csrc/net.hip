@@ -304,14 +304,15 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
         if (gdt_conv_stem_c_eligible(d)) { plan.steps[i].aug = true; plan.steps[net->input_op].aug = true; }
     }
-    for (int i = 0; i < nops && net->precision == 2; ++i) {
+    for (int i = 0; i < nops && net->precision != 0; ++i) {
         const Op& o = ops[i];
         if (o.kind != OP_CONV || !o.has_s2) continue;
         ConvLaunch d{};
         s2_geometry(net, o, N, T[o.in], d);
         d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;                  // non-null markers only
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
-        if (gdt_conv_halo_c_s2_eligible(d)) plan.steps[i].s2 = true;
+        if (net->precision == 1) { d.w = d.w_lo = (const f16*)net; d.x3_form = 2; }
+        if (net->precision == 1 ? gdt_conv_halo_x3_taps_eligible(d) : gdt_conv_halo_c_s2_eligible(d)) plan.steps[i].s2 = true;
     }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
@@ -325,8 +326,10 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
     }
     for (int j = 0; j < nops && allow_norm_fusion; ++j) {
         const Op& oj = ops[j];
-        // f16x3: the patch kernel folds a plain InstanceNorm (+ReLU) only (no residual, no write-back); GDT_X3_NORM_FOLD=0 switches that off (round 1 measured it neutral)
-        static const bool x3_fold = [] { const char* e = getenv("GDT_X3_NORM_FOLD"); return !e || atoi(e) != 0; }();
+        // f16x3: the patch kernel folds InstanceNorm (+ReLU, + residual, + write-back) while it stages; GDT_X3_NORM_FOLD=0 switches that off, 1 keeps it to the plain
+        // norm (+ReLU) without residual / write-back (the round-5 first form)
+        const char* x3_fold_env = getenv("GDT_X3_NORM_FOLD");      // (read per plan)
+        const int x3_fold = x3_fold_env ? atoi(x3_fold_env) : 2;
         if (oj.kind != OP_INORM || (net->precision == 1 && !x3_fold)) continue;
         // plain norm(+ReLU): exactly one consumer.  norm + residual (ResnetBlock output): the tensor itself is still needed
         // later (as the next block's residual), so the consuming conv also writes it out -- every other consumer must come
@@ -344,7 +347,19 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
             if (k < 0) continue;
         }
         const Op& ok = ops[k];
-        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out || (ok.cd.transposed && !plan.steps[k].ctf)) continue;
+        if (ok.kind != OP_CONV || ok.in != oj.out || ok.res == oj.out) continue;
+        if (ok.cd.transposed && !plan.steps[k].ctf) {
+            // f16x3: the four sub-pixel phase launches of a transposed conv read the same input; each applies the norm while it stages (conv_igemm_x3.hip)
+            bool all = net->precision == 1 && x3_fold >= 2 && !wb && oj.res < 0 && !ok.phases.empty();
+            for (size_t p = 0; p < ok.phases.size() && all; ++p) {
+                ConvLaunch d{};
+                conv_geometry(net, ok, ok.phases[p], N, T[ok.in], d);
+                d.w_lo = (const f16*)net;
+                all = gdt_conv_x3_norm_eligible(d);
+            }
+            if (all) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+            continue;
+        }
         if (ok.cd.out_f32_nchw && !ok.rowsplit) continue;
         if (plan.steps[k].ctf && net->precision == 2) {
             ConvLaunch d{};
@@ -362,10 +377,15 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
             d.w_cfrag = d.wmx_a = d.wmx_b = d.wmx_s = net; d.out = (f16*)net;
             d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;
             d.in_norm = (const float*)net; d.in_out = wb ? (f16*)net : nullptr;
+            if (net->precision == 1) {         // conv3x3_halo_x3.hip FORM 2: plain norm (+ReLU)
+                d.w = d.w_lo = (const f16*)net; d.x3_form = 2;
+                if (x3_fold >= 2 && !wb && gdt_conv_halo_x3_taps_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = false; }
+                continue;
+            }
             if (gdt_conv_halo_c_s2_eligible(d)) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
             continue;
         }
-        if (net->precision == 2 && ok.rowsplit) {  // f16c head: the fused 7x7 kernel normalises while it stages its fp32 input
+        if (net->precision != 0 && ok.rowsplit) {  // f16c / f16x3 head: the fused 7x7 kernel normalises while it stages its fp32 input
             ConvLaunch h{};
             conv_geometry(net, ok, ok.phases[0], N, T[ok.in], h);
             h.w_frag = ok.phases[0].has_frag ? (const f16*)net : nullptr; h.out_f32 = (float*)net; h.Cout = ok.cd.cout;
@@ -400,7 +420,8 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         d.out = (ok.cd.out_f32_nchw || ok.rowsplit) ? nullptr : (f16*)net;         // non-null marker only
         d.stats = conv_fuses_stats(ok, T[ok.in]) ? (float*)net : nullptr;          // non-null marker only
         d.out_f32 = (ok.cd.out_f32_nchw && !ok.rowsplit) ? (float*)net : nullptr;
-        const bool fold = net->precision ? (!wb && oj.res < 0 && gdt_conv_halo_x3_eligible(d))
+        const bool fold = net->precision ? (((x3_fold >= 2 || (!wb && oj.res < 0)) && gdt_conv_halo_x3_eligible(d)) ||
+                                            (x3_fold >= 2 && !wb && oj.res < 0 && !ok.rowsplit && !ok.cd.out_f32_nchw && gdt_conv_x3_norm_eligible(d)))
                                          : (gdt_conv_halo_eligible(d) || (!wb && (gdt_conv_igemm_norm_eligible(d) || irb_norm_ok(d))));
         if (fold) { plan.steps[j].norm_into = k; plan.steps[k].norm_from = j; plan.steps[j].wb = wb; }
         static const bool plan_dbg = getenv("GDT_PLAN_DEBUG") != nullptr;
@@ -886,6 +907,9 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
     if (o.rowsplit) o.rs_cout8 = (gemm_cout + 7) / 8 * 8;
     const int bn_tile = gdt_conv_bn(gemm_cout);
     o.cout_pad = (gemm_cout + bn_tile - 1) / bn_tile * bn_tile;
+    // f16x3: the phase launches of a transposed conv run on the 128-column patch kernel (conv3x3_halo_x3.hip FORM 1); 64 output channels are padded with zero rows --
+    // twice the matrix work of the layer, and still 1.8x the rate of the generic 64-column GEMM
+    if (net->precision == 1 && cd.transposed && cd.kh == 3 && cd.kw == 3 && gemm_cout == 64) o.cout_pad = 128;
 
     std::vector<float> scale, shift; bool has_shift;
     fold_bn(cd, bias, bn_gamma, bn_beta, bn_mean, bn_var, scale, shift, has_shift);
@@ -1036,7 +1060,8 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                         }
             ph.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
             if (net->precision) ph.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
-            if (net->precision != 1 && cin_pad == 64 && cd.kh == 7 && cd.kw == 7 && o.cout_pad == 32) {
+            static const bool head7_x3 = [] { const char* e = getenv("GDT_HEAD7_X3"); return !(e && atoi(e) == 0); }();      // 0: the f16x3 head stays on the generic GEMM + combine launch (A/B)
+            if ((net->precision != 1 || head7_x3) && cin_pad == 64 && cd.kh == 7 && cd.kw == 7 && o.cout_pad == 32) {
                 // conv_head7.hip keeps the whole matrix in registers: B fragment ks of lane (fh, fr) = column fr, k = ks*16 + fh*8 ..
                 const int nks = ph.Kpad / 16;
                 std::vector<f16> pf((size_t)nks * 64 * 8);
@@ -1047,6 +1072,14 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                     }
                 ph.w_frag_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
                 ph.has_frag = true;
+                if (net->precision == 1) {                         // f16x3: the lo parts in the same fragment order (conv_head7.hip X3 form: ConvLaunch::w_frag2)
+                    for (int ks = 0; ks < nks; ++ks)
+                        for (int ln = 0; ln < 64; ++ln) {
+                            const f16* src = pl.data() + (size_t)(ln & 31) * ph.Kpad + ks * 16 + (ln >> 5) * 8;
+                            std::copy(src, src + 8, pf.data() + ((size_t)ks * 64 + ln) * 8);
+                        }
+                    ph.w_frag2_off = net->blob_append(pf.data(), pf.size() * sizeof(f16));
+                }
                 if (net->precision == 2 && net->head_comp) {       // "f16ch": block-scaled correction operands of the same [32][Kpad] matrix (conv_head7.hip, second pass)
                     std::vector<float> wf((size_t)o.cout_pad * ph.Kpad, 0.f);
                     for (int kx = 0; kx < cd.kw; ++kx)
@@ -1071,7 +1104,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
         const int khw = cd.kh * cd.kw;
         pack(ph, [&](int co, int c, int t) { return weight[((size_t)co * cd.cin + c) * khw + t]; });
         o.phases.push_back(ph);
-        if (net->precision == 2 && cd.stride == 2 && cd.kh == 3 && cd.kw == 3 && cd.pad == 1 && !cd.pad_reflect && !cd.out_f32_nchw &&
+        if (net->precision != 0 && cd.stride == 2 && cd.kh == 3 && cd.kw == 3 && cd.pad == 1 && !cd.pad_reflect && !cd.out_f32_nchw &&
             residual_tensor < 0 && (cin_pad == 64 || cin_pad == 128) && cd.cin == cin_pad) {
             // shift form: K index = shift * 4cin + parity * cin + c, shift = (dy+1)*2 + (dx+1) with dy, dx in {-1, 0}, parity = py*2 + px of the
             // input pixel (2R + py, 2C + px); kernel row ky = 0 for (dy -1, py 1), 1 for (0, 0), 2 for (0, 1), none for (-1, 0); columns alike
@@ -1089,6 +1122,12 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                             wf[(size_t)co * sp.Kpad + (size_t)t * 4 * cin_pad + (size_t)par * cin_pad + c] =
                                 weight[((size_t)co * cd.cin + c) * 9 + ky * 3 + kx] * scale[co];
                     }
+            if (net->precision == 1) {          // f16x3: the same matrix split into hi / lo, row-major (conv3x3_halo_x3.hip FORM 2)
+                std::vector<f16> pk(wf.size()), pl(wf.size());
+                for (size_t i = 0; i < wf.size(); ++i) { pk[i] = (f16)wf[i]; pl[i] = (f16)((wf[i] - (float)pk[i]) * 2048.f); }
+                sp.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+                sp.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
+            } else {
             std::vector<unsigned char> ma, mb; std::vector<unsigned> msc; std::vector<f16> wc;
             pack_mx(wf, o.s2_cout_pad, sp.Kpad, ma, mb, msc, wc);
             sp.wc_off = net->blob_append(wc.data(), wc.size() * sizeof(f16));
@@ -1096,6 +1135,7 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
             sp.wmx_b_off = net->blob_append(mb.data(), mb.size());
             sp.wmx_s_off = net->blob_append(msc.data(), msc.size() * sizeof(unsigned));
             sp.has_mx = true;
+            }
             if (has_shift) {
                 std::vector<float> bp(o.s2_cout_pad, 0.f);
                 std::copy(shift.begin(), shift.end(), bp.begin());
@@ -1632,6 +1672,14 @@ int exec_step(gdt_net* net, LevelCtx& c, const Step& stp, hipStream_t st, Deferr
                     s2_geometry(net, o, n, ti, d);
                     d.bias = o.has_bias ? (const float*)(net->dev_blob + o.s2_bias_off) : nullptr;
                     d.out = tptr(o.out); d.out_f32 = nullptr; d.w = nullptr; d.w_lo = nullptr; d.w_frag = nullptr;
+                    d.stats_tile_base = 0;
+                    if (net->precision == 1) {      // f16x3: the patch kernel over the same view (conv3x3_halo_x3.hip FORM 2)
+                        d.w = (const f16*)(net->dev_blob + o.s2.w_off); d.w_lo = (const f16*)(net->dev_blob + o.s2.w_lo_off); d.x3_form = 2;
+                        int variant = 0;
+                        rc = gdt_launch_conv_x3(d, st, &variant);
+                        if (net->profiling) net->last_variant[stp.op] = variant;
+                        break;
+                    }
                     d.w_cfrag = net->dev_blob + o.s2.wc_off; d.wmx_a = net->dev_blob + o.s2.wmx_a_off; d.wmx_b = net->dev_blob + o.s2.wmx_b_off; d.wmx_s = net->dev_blob + o.s2.wmx_s_off;
                     d.c_lo_exp = 12; d.c_hi_exp = 0;
                     d.stats_tile_base = 0;
@@ -1661,9 +1709,10 @@ int exec_step(gdt_net* net, LevelCtx& c, const Step& stp, hipStream_t st, Deferr
                     d.stats_tile_base = phase_idx * (d.M / 128);
                     ++phase_idx;
                     int variant = 0;
-                    if (o.rowsplit && net->precision != 1) {           // fused head kernel (f16c: fp32 input, rounded once while staging): GEMM over the kernel rows + combine + activation in one launch
+                    if (o.rowsplit) {           // fused head kernel (f16c: fp32 input, rounded once while staging; f16x3: split twice): GEMM over the kernel rows + combine + activation in one launch
                         ConvLaunch h = d;
                         h.out = nullptr; h.out_f32 = (float*)outputs[o.slot]; h.Cout = o.cd.cout; h.act = o.cd.act; h.in_f32 = f32;
+                        h.w_frag2 = (net->precision == 1 && ph.has_frag) ? (const f16*)(net->dev_blob + ph.w_frag2_off) : nullptr;
                         h.bias = o.has_bias ? (const float*)(net->dev_blob + o.rs_bias_off) : nullptr;
                         if (gdt_conv_head7_eligible(h)) {
                             rc = gdt_launch_conv_head7(h, st);

@@ -158,7 +158,7 @@ class HipNet:
         return int(math.floor(float(h * scale))), int(math.floor(float(w * scale)))
 
     #: knobs the planner reads when it plans a geometry (A/B inside one process): part of the key of the per-geometry cache below
-    _PLAN_KNOBS = ("GDT_CONV_XEXP", "GDT_XEXP_CHAIN", "GDT_CONV_BNECK")
+    _PLAN_KNOBS = ("GDT_CONV_XEXP", "GDT_XEXP_CHAIN", "GDT_CONV_BNECK", "GDT_CONV_HALO_X3", "GDT_CONV_HALO_X3_FORMS", "GDT_X3_NORM_FOLD")
 
     def _geometry(self, n, rh, rw):
         """(workspace bytes, output shapes) of a geometry, planned once: every query plans the whole graph (make_plan, csrc/net.hip: ~0.1 ms for ResNet-101), and a

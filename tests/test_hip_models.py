@@ -232,6 +232,36 @@ def test_generator_exact_mode_is_exact_with_the_fp32_class_stem(cuda_device):
 
 
 @pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_exact_mode_patch_kernel_forms(cuda_device, monkeypatch, norm):
+    """Round 5: the exact mode's shift layers and head on the patch kernels -- conv3x3_halo_x3.hip FORM 2 (stride 2 over the space-to-depth view, 932128), FORM 1 (the phase
+    launches of the transposed convs, 931128; 64 output channels padded to the 128-column tile), conv_head7.hip X3 (920007) -- with every InstanceNorm folded into the
+    consumer's staging (norm + residual + write-back in the resblocks).  They engage from 512 tiles per launch (batch 64 at 256^2: bench.py's exact_mode); forced here at
+    batch 4 and checked at the raw conv outputs behind each folded norm, the resblock outputs and pre-tanh: 1e-5 of the fp32 oracle, the mode's promise"""
+    from gandtr_amd.engine import build_generator
+    monkeypatch.setenv("GDT_CONV_HALO_X3", "2")
+    monkeypatch.setenv("GDT_CONV_HALO_X3_FORMS", "2")
+    sd = synth.generator_state(0, norm, gain=0.02)
+    x = synth.synth_input(13, (4, 3, 256, 256), 1.0)
+    taps = (1, 4, 7, 10, 14, 18, 19, 22)
+    ref, feats = O.resnet_generator(x, sd, norm, 9, taps=taps, pre_tanh=True)
+    net = build_generator(sd, cuda_device, taps=taps, precision="f16x3", pre_tanh=True)
+    net.set_profiling(True)
+    outs = net.forward(x.to(cuda_device))
+    torch.cuda.synchronize()
+    ran = {v for k, v, ms, fl in net.profile() if k == 1}
+    assert {930128, 931128, 932128, 920007} <= ran, sorted(ran)
+    generic = {v for v in ran if 300000 <= v < 400000}                      # what is left on the generic three-pass GEMM: nothing (BatchNorm variant: its ReLU-fused stem)
+    assert generic <= (set() if norm == "instance" else {300064}), sorted(ran)
+    if norm == "instance":
+        s = net.plan_summary(4, 256, 256)
+        assert s["norms_folded"] == 20, s          # 23 InstanceNorms: the last resblock's (residual, into the transposed conv) keeps its own pass, and so do the two whose output is tapped here (10, 14)
+    worst = max(_rel(outs[net.tap_slots[t]].cpu(), feats[t]) for t in taps)
+    pre = _rel(outs[net.out_slot].cpu(), ref)
+    print("exact mode (f16x3), %s norm, patch-kernel forms forced at batch 4: worst tap %.2e, pre-tanh %.2e" % (norm, worst, pre))
+    assert worst < 1e-5 and pre < 1e-5, (worst, pre)
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
 def test_generator_tiny_f16x3(cuda_device, norm):
     from gandtr_amd.engine import build_generator
     sd = synth.generator_state(0, norm, ngf=8, n_blocks=2)

@@ -142,3 +142,13 @@ def test_planner_fusion_decisions_at_the_benchmarked_geometries(monkeypatch):
     assert g["norms_folded"] == 23 and g["transposed_fused"] == 2 and g["stride2_shift"] == 2 and g["conv_launches"] == 24, g
     g1 = gen.plan_summary(1, 64, 64)
     assert g1["norms_folded"] < 23, g1                                         # a single small image: the generic kernels, own normalisation passes
+    # the exact mode ("f16x3") at the benchmarked batch: the stride-2 convs as shift forms on the patch kernel, 22 of the 23 norms folded (resblock norms with their
+    # residual and write-back; the last resblock's feeds the phase launches of a transposed conv and keeps its own pass)
+    for k in ("GDT_CONV_HALO_X3", "GDT_CONV_HALO_X3_FORMS", "GDT_X3_NORM_FOLD", "GDT_HEAD7_X3"):
+        monkeypatch.delenv(k, raising=False)
+    exact = engine.build_generator(synth.generator_state(0, "instance"), DEV, precision="f16x3", finalize=False)
+    e = exact.plan_summary(64, 256, 256)
+    assert e["norms_folded"] == 22 and e["stride2_shift"] == 2 and e["transposed_fused"] == 0, e
+    monkeypatch.setenv("GDT_X3_NORM_FOLD", "1")                                # the first form: plain norm + ReLU into the stride-1 patch kernel only
+    assert exact.plan_summary(64, 256, 256)["norms_folded"] == 10                # (9 inside the resblocks + the head's)
+    monkeypatch.delenv("GDT_X3_NORM_FOLD")
