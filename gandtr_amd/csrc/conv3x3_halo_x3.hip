@@ -22,6 +22,24 @@
 
 #include "gdt_common.h"
 
+// Where a step's time goes (round 5, FORM 0 at 64 x 256^2: 0.93 ms per launch, 18 launches = 70 % of the exact mode's forward; 2 waves per SIMD, one step = one tap
+// of one 32-channel chunk = 24 MFMAs per wave behind one workgroup barrier):
+//   * timing-only ablations (-DGDT_X3_ABL=bits: 1 no halo loads after the first chunk, 2 no MFMAs, 4 no weight staging after the first step; 18 launches): 17.1 ms as
+//     is; 15.2 / 10.8 / 15.4 with bit 1 / 2 / 4 alone, 14.0 with 1 + 4, 6.5 with all three;
+//   * s_memtime stamps, shader cycles per step, waves 0-3 / 4-7: barrier wait 880 / 160, fragment reads + load issue 920 / 1830, the 24 MFMAs 780 / 860 (full rate
+//     while they run), staging arithmetic 650 / 400: 3250 in all, of which the matrix pipe runs 1640.  The older wave of a SIMD issues first; the younger one's reads and
+//     MFMAs queue behind it; nothing of the front part or the staging lies under an MFMA;
+//   * SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32 (the 64-byte halo rows; conv3x3_halo_c16.hip's pixel <-> column map has 0.02), LDS active 21 % of the CU's cycles;
+//   * tried, all within +-3 % or slower (each passed the parity tests): both 16-k halves' fragment reads issued ahead of the MFMAs; the two waves of a SIMD running
+//     MFMAs / staging in opposite order; fragments pipelined ACROSS the step barrier with a third weight stage (the next step's first set read under this step's
+//     second MFMA half), as written and with a branch-free front part (every address made valid by mask arithmetic, so that the front is one basic block: the
+//     compiler still puts an lgkmcnt(0) in front of the first MFMA of the loop body, and the unconditional loads cost 1.1 ms).  What this loop needs is what the
+//     compensated kernels got in rounds 3-4 (hand-laid MFMA / LDS / VALU interleave in inline asm with counted waits); as HIP source it stays at 0.42 of the mode's
+//     three-pass ceiling -- 331 TFLOP/s algorithmic = 1.0 PFLOP/s of MFMA work, the rate the compensated resblock kernel also runs at.
+#ifndef GDT_X3_ABL
+#define GDT_X3_ABL 0
+#endif
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
         p.v = p.rv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r * 64 + hrow >= HALO_ROWS_PAD) return p;
         if (!((a_ok >> r) & 1u)) return p;
+        if ((GDT_X3_ABL & 1) && chunk > 0) return p;
         const long off = ((long)(a_pix[r] + pix_of(chunk)) << lcr) + chan_of(chunk);
         p.v = *(const float4*)(in + off);
         if (!BURST && inres) p.rv = *(const float4*)(inres + off);
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 for (int r = 0; r < 6; ++r) pend[BURST ? r : 0] = load_piece(c + 1, r);
             }
         }
-        if (more) issue_b(nt * d.Cin + (nc << 5), (s + 1) & 1);
+        if (more && !(GDT_X3_ABL & 4)) issue_b(nt * d.Cin + (nc << 5), (s + 1) & 1);
         const char* Ah = smem + (c & 1) * STAGE_A;
         const char* Bh = smem + 2 * STAGE_A + (s & 1) * STAGE_B;
         const int ty = (t * d.invTW) >> 16, tx = t - ty * d.TW;
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 bh[j] = *(const f16x8*)(Bh + o); bl[j] = *(const f16x8*)(Bh + B_BYTES + o);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < ((GDT_X3_ABL & 2) ? 0 : TM); ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
