@@ -253,6 +253,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
     for (int j = 0; j < TN; ++j) {
         const int lcol = wn * WTN + j * 32 + fr;
         const int col = tile_n * BN + lcol;
+        // (paired phases of a transposed conv: the wave's 64 columns are one phase -- its own output pixel offset, channels 0-63)
+        const bool half = d.pair_cout > 0 && lcol >= d.pair_cout;
+        const int co = half ? col - d.pair_cout : col;
+        const int ooy = half ? d.ooy2 : d.ooy, oox = half ? d.oox2 : d.oox;
         const float bv = d.bias ? d.bias[col] : 0.f;
         float s1 = 0.f, s2 = 0.f;
         float rr[TM][16];                      // residual values of this column: all loads issued before any is consumed
@@ -263,8 +267,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 for (int e = 0; e < 16; ++e) {
                     const int row = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                     const int y = y0 + (row >> 4), x = x0 + (row & 15);
-                    const bool ok = y < GH && x < GW && col < d.Cout;
-                    rr[i][e] = resp[ok ? (((long)n * d.OH + y * d.osy + d.ooy) * d.OW + x * d.osx + d.oox) * d.Cout + col : 0];
+                    const bool ok = y < GH && x < GW && co < d.Cout;
+                    rr[i][e] = resp[ok ? (((long)n * d.OH + y * d.osy + ooy) * d.OW + x * d.osx + oox) * d.Cout + co : 0];
                 }
         }
 #pragma unroll
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
                 float v = acc[i][j][e] + accl[i][j][e] * LO_INV + bv;
                 s1 += v; s2 += v * v;
                 const int y = y0 + (row >> 4), x = x0 + (row & 15);
-                if (y >= GH || x >= GW || col >= d.Cout) continue;
-                const long off = (((long)n * d.OH + y * d.osy + d.ooy) * d.OW + x * d.osx + d.oox) * d.Cout + col;
+                if (y >= GH || x >= GW || co >= d.Cout) continue;
+                const long off = (((long)n * d.OH + y * d.osy + ooy) * d.OW + x * d.osx + oox) * d.Cout + co;
                 if (resp) v += rr[i][e];
                 if (d.relu) v = fmaxf(v, 0.f);
                 outp[off] = v;
@@ -293,8 +297,10 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_x3_kernel(const ConvLaunch d)
             const float s1 = sl[((rec * 2) * BN + col) * 2 + 0] + sl[((rec * 2 + 1) * BN + col) * 2 + 0];
             const float s2 = sl[((rec * 2) * BN + col) * 2 + 1] + sl[((rec * 2 + 1) * BN + col) * 2 + 1];
             const int gcol = tile_n * BN + col;
-            if (gcol < d.Cout) {
-                float* dst = d.stats + ((long)(d.stats_tile_base + tile_m * 2 + rec) * 2) * d.Cout + gcol;
+            const bool half = d.pair_cout > 0 && col >= d.pair_cout;            // (paired phases: the second one's records lie one set = M / 128 records further on)
+            const int gco = half ? gcol - d.pair_cout : gcol;
+            if (gco < d.Cout) {
+                float* dst = d.stats + ((long)(d.stats_tile_base + (half ? d.M / 128 : 0) + tile_m * 2 + rec) * 2) * d.Cout + gco;
                 dst[0] = s1; dst[d.Cout] = s2;
             }
         }
@@ -324,6 +330,7 @@ bool gdt_conv_halo_x3_taps_eligible(const ConvLaunch& d) {
     const char* e = getenv("GDT_CONV_HALO_X3_FORMS");           // 0 off (A/B: the generic GEMM), 1 auto, 2 force (read per call)
     const int mode = e ? atoi(e) : 1;
     if (mode == 0 || !d.w_lo || d.out_f32 || d.in_res || d.in_out || d.pool2 || d.CoutPad % 128 != 0 || d.osy < 1 || d.osx < 1) return false;
+    if (d.pair_cout && (d.pair_cout != 64 || d.CoutPad != 128 || d.Cout != 64 || d.x3_form != 0)) return false;      // paired phases: one 128-column tile = 2 x 64 channels
     if (d.x3_form == 2) {
         const bool shape = d.ntaps == 4 && d.TW == 2 && d.dy0 == -1 && d.dys == 1 && d.dx0 == -1 && d.dxs == 1 && d.sy == 2 && d.sx == 2 && d.osy == 1 && d.osx == 1 &&
                            d.ooy == 0 && d.oox == 0 && !d.pad_reflect && !(d.H & 1) && !(d.W & 1) && d.OH == d.H / 2 && d.OW == d.W / 2 && d.OHg == d.OH && d.OWg == d.OW &&

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
             const int off = a_base[ks >> 2] ^ ((ks & 3) << 5);
             f[0] = *(const f16x8*)(smem + off);
             f[1] = *(const f16x8*)(smem + off + NWAVE * 32 * 128);
-            if (STREAM) f[2] = *(const f16x8*)(smem + off + b2 * (NWAVE * 32 * 128));          // (b2 = 1 for the waves with two blocks: a duplicate, discarded)
+            if (MX) f[2] = *(const f16x8*)(smem + off + b2 * (NWAVE * 32 * 128));          // (b2 = 1 for the waves with two blocks: a duplicate, discarded)
             else if (nb == 3) f[2] = *(const f16x8*)(smem + off + 2 * NWAVE * 32 * 128);
         };
         if (!(d.dbg & 2)) {
@@ -302,11 +302,12 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                 const f16x8 wk = STREAM ? wring[ks % WRING] : bw[ks % NBW];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][0], wk, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][1], wk, acc[1], 0, 0, 0);
-                if (STREAM || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);
+                if (MX || nb == 3) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, acc[2], 0, 0, 0);
                 if (X3) {                       // a_hi w_lo
                     const f16x8 wl = wring_lo[X3 ? ks % WRING : 0];
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wl, accl[X3 ? b : 0], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wl, accl[X3 ? b : 0], 0, 0, 0);
+                    if (nb == 3) accl[X3 ? 2 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wl, accl[X3 ? 2 : 0], 0, 0, 0);
                 }
             }
         }
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(NT, 2) void conv_head7_kernel(const ConvLaunch d, c
                 if (ks + WRING - 1 < 4 * KT) load_w(ks + WRING - 1);
                 const f16x8 wk = wring[ks % WRING];
 #pragma unroll
-                for (int b = 0; b < 3; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wk, accl[X3 ? b : 0], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) accl[X3 ? b : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][b], wk, accl[X3 ? b : 0], 0, 0, 0);
+                if (nb == 3) accl[X3 ? 2 : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[ks % PF][2], wk, accl[X3 ? 2 : 0], 0, 0, 0);
             }
             lds_barrier();                             // the lo plane has been consumed
 #pragma unroll

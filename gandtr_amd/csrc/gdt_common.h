@@ -114,6 +114,8 @@ struct ConvLaunch {
     // 4 blocks]; lane (n, blk) of a correction operand = 32 e2m3 values of fp16(w) (blk 0, 2) / w - fp16(w) (blk 1, 3) of k 0-31 (blk 0, 1) / 32-63 (blk 2, 3)
     const void* w_c16;
     int c_lo_exp, c_hi_exp;
+    int pair_cout, ooy2, oox2;    // conv3x3_halo_x3.hip FORM 1: > 0 = the 128 GEMM columns are TWO sub-pixel phases of a transposed conv with pair_cout (64) output channels each;
+                                  //      the second half writes output pixel (oy * osy + ooy2, ox * osx + oox2) and its statistics one record set (M / 128 records) further on
     int x3_form;                  // conv3x3_halo_x3.hip: 2 = Conv2d(k3,s2,p1) as 2 x 2 shifts over the virtual space-to-depth view (Cin counts the 4 parities); else 0
     int in_f32;                   // conv_head7.hip: `in` is the fp32 NHWC tensor of the f16c mode (rounded to fp16 once, while staging)
     int stagger_us;               // conv3x3_halo_c.hip: start-up delay step between the four workgroup phase groups (0: none)

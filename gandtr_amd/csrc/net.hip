@@ -37,6 +37,7 @@ struct PackedPhase {
     size_t w16_off = 0; bool has_mx16 = false;   // ... in the 16 x 16 fragment order, one record per (64 channels, 64 k) (ConvLaunch::w_c16)
     int ntaps = 0, TW = 1, dy0 = 0, dys = 1, dx0 = 0, dxs = 1, Kpad = 0;
     int ooy = 0, oox = 0;
+    int ooy2 = 0, oox2 = 0;           // paired phases (Op::pairs): output pixel offset of the second half
 };
 
 struct Op {
@@ -61,6 +62,9 @@ struct Op {
     bool has_ctf = false; PackedPhase ctf; size_t ctf_bias_off = 0;
     // f16c: Conv2d(k3, s2, p1) as a 2x2-shift conv over the virtual space-to-depth input (conv3x3_halo_c.hip, FORM 2): K = 4 shifts x 4 cin
     bool has_s2 = false; PackedPhase s2; size_t s2_bias_off = 0; int s2_cout_pad = 0;
+    // f16x3, ConvTranspose2d(k3,s2,p1,op1) with 64 output channels: the phases (py, 0) and (py, 1) as ONE 128-column GEMM per py over the union of their taps
+    // (conv3x3_halo_x3.hip FORM 1 with ConvLaunch::pair_cout): 3/4 of the products are useful, and the input patch is staged twice instead of four times
+    bool has_pairs = false; std::vector<PackedPhase> pairs; size_t pair_bias_off = 0;
     // fp16 mode: a 1x1 expand conv whose residual is the output of a 1x1 projection conv (ResNet Bottleneck shortcut, stride 1 or 2) carries the two
     // weight matrices K-concatenated (conv1x1_rb.hip, CAT form): kcat_ds = index of the projection op
     int kcat_ds = -1; size_t kcat_frag_off = 0, kcat_bias_off = 0;
@@ -160,6 +164,7 @@ struct Step {
     bool ctf;        // CONV (transposed): runs as the single fused-phase launch
     bool aug;        // INPUT / CONV (f16c): the image is packed as augmented fp16 pixel words for the stem kernel's f16c form
     bool s2;         // CONV (stride 2, f16c): runs as the shift form over the virtual space-to-depth input
+    bool ctp;        // CONV (transposed, f16x3, 64 output channels): two paired-phase launches (Op::pairs) instead of four phase launches
     int pool_into;   // CONV: index of the MAXPOOL(2,2) op whose output this conv writes directly (-1: none)
     bool skip;       // MAXPOOL fused into its producer; CONV: second / third conv of a fused Bottleneck (done by the first one's launch)
     bool bneck;      // CONV: first conv of a Bottleneck that runs as ONE launch (conv_bneck.hip): ops i, i + 1, i + 2 (identity shortcut) ...
@@ -217,6 +222,12 @@ void s2_geometry(const gdt_net* net, const Op& o, int n, const Tensor& ti, ConvL
     d.CoutPad = o.s2_cout_pad; d.pad_reflect = 0;
 }
 
+// a paired-phase launch of a transposed conv (see Op::pairs): 128 GEMM columns = 2 phases x 64 channels
+void pair_geometry(const gdt_net* net, const Op& o, const PackedPhase& pp, int n, const Tensor& ti, ConvLaunch& d) {
+    conv_geometry(net, o, pp, n, ti, d);
+    d.CoutPad = 128; d.pair_cout = 64; d.ooy2 = pp.ooy2; d.oox2 = pp.oox2;
+}
+
 // shape inference, fusion decisions and workspace layout for one geometry; fills tensors[*].{H,W,off,bytes}
 // direct_ok: the call does not resize its input (forward knows; the size queries plan the general case, whose footprint is the larger one)
 int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = false) {
@@ -225,7 +236,7 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
     const int nops = (int)ops.size();
     for (auto& t : T) { t.H = t.W = 0; t.last_use = -1; t.off = 0; t.bytes = 0; }
     plan.steps.assign(nops, Step{});
-    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; plan.steps[i].xexp = false; plan.steps[i].xchain = -1; }
+    for (int i = 0; i < nops; ++i) { plan.steps[i].op = i; plan.steps[i].norm_into = plan.steps[i].norm_from = -1; plan.steps[i].ctf = false; plan.steps[i].s2 = false; plan.steps[i].ctp = false; plan.steps[i].aug = false; plan.steps[i].stats_sets = 1; plan.steps[i].pool_into = -1; plan.steps[i].skip = false; plan.steps[i].bneck = false; plan.steps[i].bneck_ds = -1; plan.steps[i].bneck_a = i; plan.steps[i].kcat = false; plan.steps[i].direct = false; plan.steps[i].xexp = false; plan.steps[i].xchain = -1; }
 
     // ---- pass 1: shapes
     for (int i = 0; i < nops; ++i) {
@@ -313,6 +324,19 @@ int make_plan(gdt_net* net, int N, int RH, int RW, Plan& plan, bool direct_ok = 
         d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
         if (net->precision == 1) { d.w = d.w_lo = (const f16*)net; d.x3_form = 2; }
         if (net->precision == 1 ? gdt_conv_halo_x3_taps_eligible(d) : gdt_conv_halo_c_s2_eligible(d)) plan.steps[i].s2 = true;
+    }
+    for (int i = 0; i < nops && net->precision == 1; ++i) {
+        const Op& o = ops[i];
+        if (o.kind != OP_CONV || !o.has_pairs) continue;
+        bool all = true;
+        for (const PackedPhase& pp : o.pairs) {
+            ConvLaunch d{};
+            pair_geometry(net, o, pp, N, T[o.in], d);
+            d.w = d.w_lo = (const f16*)net; d.out = (f16*)net;                              // non-null markers only
+            d.stats = conv_fuses_stats(o, T[o.in]) ? (float*)net : nullptr;
+            all = all && gdt_conv_halo_x3_taps_eligible(d);
+        }
+        plan.steps[i].ctp = all;
     }
     auto irb_norm_ok = [&](ConvLaunch d) { d.in_norm = (const float*)net; return gdt_conv_igemm_rb_eligible(d); };     // marker only
     // ---- pass 2: fold InstanceNorm(+ReLU) into the input staging of its only consumer when that is a halo-kernel conv
@@ -907,9 +931,6 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
     if (o.rowsplit) o.rs_cout8 = (gemm_cout + 7) / 8 * 8;
     const int bn_tile = gdt_conv_bn(gemm_cout);
     o.cout_pad = (gemm_cout + bn_tile - 1) / bn_tile * bn_tile;
-    // f16x3: the phase launches of a transposed conv run on the 128-column patch kernel (conv3x3_halo_x3.hip FORM 1); 64 output channels are padded with zero rows --
-    // twice the matrix work of the layer, and still 1.8x the rate of the generic 64-column GEMM
-    if (net->precision == 1 && cd.transposed && cd.kh == 3 && cd.kw == 3 && gemm_cout == 64) o.cout_pad = 128;
 
     std::vector<float> scale, shift; bool has_shift;
     fold_bn(cd, bias, bn_gamma, bn_beta, bn_mean, bn_var, scale, shift, has_shift);
@@ -1159,6 +1180,38 @@ int gdt_net_conv(gdt_net* net, int in_tensor, const gdt_conv_desc* desc, const f
                 });
                 o.phases.push_back(ph);
             }
+        if (net->precision == 1 && cd.cout == 64 && cin_pad % 32 == 0 && cd.cin == cin_pad && residual_tensor < 0) {
+            for (int py = 0; py < 2; ++py) {
+                PackedPhase pp;
+                const int th = py ? 2 : 1, tw = 2;
+                pp.ntaps = th * tw; pp.TW = tw; pp.dy0 = py ? 1 : 0; pp.dys = -1; pp.dx0 = 1; pp.dxs = -1;
+                pp.ooy = py; pp.oox = 0; pp.ooy2 = py; pp.oox2 = 1;
+                pp.Kpad = pp.ntaps * cin_pad;
+                std::vector<f16> pk((size_t)128 * pp.Kpad, (f16)0.f), pl(pk.size(), (f16)0.f);
+                for (int px = 0; px < 2; ++px)
+                    for (int t = 0; t < pp.ntaps; ++t) {
+                        const int dy = pp.dy0 + (t / tw) * pp.dys, dx = pp.dx0 + (t % tw) * pp.dxs;
+                        const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1), kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+                        if (ky < 0 || kx < 0) continue;                       // (this phase does not see this shift: a zero block)
+                        for (int co = 0; co < cd.cout; ++co)
+                            for (int c = 0; c < cd.cin; ++c) {
+                                const float w = weight[(((size_t)c * cd.cout + co) * 3 + ky) * 3 + kx] * scale[co];
+                                const size_t idx = (size_t)(px * 64 + co) * pp.Kpad + (size_t)t * cin_pad + c;
+                                pk[idx] = (f16)w;
+                                pl[idx] = (f16)((w - (float)pk[idx]) * 2048.f);
+                            }
+                    }
+                pp.w_off = net->blob_append(pk.data(), pk.size() * sizeof(f16));
+                pp.w_lo_off = net->blob_append(pl.data(), pl.size() * sizeof(f16));
+                o.pairs.push_back(pp);
+            }
+            if (has_shift) {
+                std::vector<float> b2(128);
+                for (int i = 0; i < 128; ++i) b2[i] = shift[i & 63];
+                o.pair_bias_off = net->blob_append(b2.data(), b2.size() * sizeof(float));
+            }
+            o.has_pairs = true;
+        }
         if (net->precision != 1 && cin_pad % 64 == 0 && (4 * cd.cout) % 256 == 0 && 256 % cd.cout == 0 && cd.cout >= 64 && residual_tensor < 0) {
             // fused form: GEMM column -> (phase py * 2 + px, co) by gdt_ctf_column(), k = (dy * 2 + dx) * cin + c over the 2x2 input
             // shifts; a (shift, phase) pair that does not occur is a zero block (16 blocks, 9 non-zero) the kernel skips
@@ -1685,6 +1738,22 @@ int exec_step(gdt_net* net, LevelCtx& c, const Step& stp, hipStream_t st, Deferr
                     d.stats_tile_base = 0;
                     rc = gdt_launch_conv_halo_c_s2(d, st);
                     if (net->profiling) net->last_variant[stp.op] = 990256;
+                    break;
+                }
+                if (stp.ctp) {                  // f16x3 transposed conv, 64 output channels: the phases (py, 0) and (py, 1) as one 128-column launch per py
+                    int pi = 0;
+                    for (const PackedPhase& pp : o.pairs) {
+                        pair_geometry(net, o, pp, n, ti, d);
+                        d.bias = o.has_bias ? (const float*)(net->dev_blob + o.pair_bias_off) : nullptr;
+                        d.out = tptr(o.out); d.out_f32 = nullptr;
+                        d.w = (const f16*)(net->dev_blob + pp.w_off); d.w_lo = (const f16*)(net->dev_blob + pp.w_lo_off); d.w_frag = nullptr;
+                        d.stats_tile_base = 2 * pi * (d.M / 128);          // (record sets in phase order (0,0) (0,1) (1,0) (1,1): the kernel puts the second half one set further on)
+                        ++pi;
+                        int variant = 0;
+                        rc = gdt_launch_conv_x3(d, st, &variant);
+                        if (net->profiling) net->last_variant[stp.op] = variant;
+                        if (rc != GDT_OK) break;
+                    }
                     break;
                 }
                 int phase_idx = 0;

@@ -312,6 +312,8 @@ class HipNet:
             first_on_cur = os.environ.get("GANDTR_HIP_FIRST_ON_CURRENT", "0") == "1"
             results = [None] * len(inputs)
             order = (list(range(1, len(inputs))) + [0]) if first_on_cur else list(range(len(inputs)))
+            # (the order in which the host enqueues the levels -- as given, smallest first, largest first -- makes no difference: hub scales at 8 x 1024^2 6.36 / 6.56 /
+            # 6.43 ms, {1, 1/sqrt 2, sqrt 2} 13.68 / 13.64 / 13.67 ms)
             for k in order:
                 x, scale = inputs[k]
                 if x.dim() != 4 or x.shape[1] != self.in_channels:
