@@ -33,9 +33,13 @@
 //   * tried, all within +-3 % or slower (each passed the parity tests): both 16-k halves' fragment reads issued ahead of the MFMAs; the two waves of a SIMD running
 //     MFMAs / staging in opposite order; fragments pipelined ACROSS the step barrier with a third weight stage (the next step's first set read under this step's
 //     second MFMA half), as written and with a branch-free front part (every address made valid by mask arithmetic, so that the front is one basic block: the
-//     compiler still puts an lgkmcnt(0) in front of the first MFMA of the loop body, and the unconditional loads cost 1.1 ms).  What this loop needs is what the
-//     compensated kernels got in rounds 3-4 (hand-laid MFMA / LDS / VALU interleave in inline asm with counted waits); as HIP source it stays at 0.42 of the mode's
-//     three-pass ceiling -- 331 TFLOP/s algorithmic = 1.0 PFLOP/s of MFMA work, the rate the compensated resblock kernel also runs at.
+//     compiler still puts an lgkmcnt(0) in front of the first MFMA of the loop body, and the unconditional loads cost 1.1 ms); and a loop whose steps BEGIN with
+//     their MFMAs (first fragment set read at the end of the previous step, second set behind the first MFMA half; the ISA shows 12 MFMAs, 8 reads, the global issue,
+//     12 MFMAs, 8 reads, staging, barrier -- exactly as meant): 2885 images/s against 2952 for this plain loop, alternating;
+//   * why none of it moves: the forward runs AT THE POWER CAP.  tools/x3_clock.py, 3 s of exact-mode forwards: 1376 W of the 1400 W cap, 2.07 GHz (plain loop) /
+//     2.10 GHz (MFMA-first loop, and slower); the default mode's forward 1361 W at 1.96 GHz.  A better schedule is handed back as clock; what counts is energy per
+//     result -- fewer instructions and bytes (the 3-VALU split below was worth 1-2 %), not fewer stalls.  The kernel stays at 0.42 of the mode's three-pass ceiling:
+//     331 TFLOP/s algorithmic = 1.0 PFLOP/s of MFMA work, the rate the compensated resblock kernel also runs at.
 #ifndef GDT_X3_ABL
 #define GDT_X3_ABL 0
 #endif
