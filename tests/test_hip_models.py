@@ -275,14 +275,26 @@ def test_generator_tiny_f16x3(cuda_device, norm):
         assert _rel(outs[net.tap_slots[t]].cpu(), feats[t]) < 1e-4, t
 
 
+@pytest.mark.parametrize("forced", [False, True])
 @pytest.mark.parametrize("arch", ["vgg16", "resnet101"])
-def test_embedder_f16x3(cuda_device, arch):
+def test_embedder_f16x3(cuda_device, monkeypatch, arch, forced):
+    """forced: the exact mode's patch kernels below their tile thresholds -- every 3x3 conv from 32 input channels on conv3x3_halo_x3.hip FORM 0, ResNet-101's 128 -> 128
+    stride-2 conv (BatchNorm folded, ReLU in the epilogue) on FORM 2, on maps the 16 x 16 patches do not tile (40 x 48, 20 x 24, 10 x 12: clamped loads, masked stores)"""
     from gandtr_amd.engine import build_embedder
+    if forced:
+        monkeypatch.setenv("GDT_CONV_HALO_X3", "2")
+        monkeypatch.setenv("GDT_CONV_HALO_X3_FORMS", "2")
     sd = synth.vgg16_state(0, p=3.0) if arch == "vgg16" else synth.resnet101_state(0, p=2.37)
     x = synth.synth_input(3, (2, 3, 160, 192))
     ref = O.image_retrieval_forward(x, sd, arch).t().contiguous()
     net = build_embedder(sd, cuda_device, precision="f16x3")
+    net.set_profiling(True)
     got = net.forward(x.to(cuda_device))[net.out_slot].cpu()
+    ran = {v for k, v, ms, fl in net.profile() if k == 1}
+    if forced:
+        assert 930128 in ran and (arch == "vgg16" or 932128 in ran), sorted(ran)
+    else:
+        assert not ({930128, 931128, 932128} & ran), sorted(ran)
     assert float((got - ref).abs().max()) < 2e-5
 
 
